@@ -1,0 +1,218 @@
+/*
+ * include/lvq.h -- C ABI of liblvq_hip.so, the MI355X (gfx950) implementation of the LiDAR-vision
+ * fusion hot path of Advaith-Sajeev/LiDAR-Vision-VQA.
+ *
+ * The reference has NO FFI on this path: its boundary is Python nn.Module / numpy duck-typing
+ * (SURVEY.md 8b).  Each entry point below therefore names the reference Python interface whose
+ * arithmetic it replaces (file:line relative to /root/reference/src/); the Python host side in
+ * lidar-vision-vqa_amd/{lidar,fusion,head}/ mirrors those interfaces 1:1 and binds these symbols
+ * through ctypes (lidar-vision-vqa_amd/_ffi.py).  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions (all functions):
+ *   - extern "C", plain pointers and sizes, no torch / HIP types in the signatures
+ *     (`lvq_stream_t` is a hipStream_t passed as void*; NULL = the null stream).
+ *   - every pointer is a DEVICE pointer unless the parameter comment says "host".
+ *   - the caller owns every buffer, including the workspace whose size is queried first;
+ *     nothing is allocated, freed or synchronised inside a call -> stream-ordered, asynchronous,
+ *     graph-capturable, no global state (thread-safe per stream).
+ *   - return value: LVQ_OK (0) or a negative LVQ_E* code; never throws, never exits.
+ *   - rows are contiguous, row-major; "bf16" is the upper 16 bits of an IEEE fp32 (uint16_t).
+ */
+#ifndef LVQ_H
+#define LVQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *lvq_stream_t;
+typedef uint16_t lvq_bf16;
+
+enum {
+    LVQ_OK = 0,
+    LVQ_EINVAL = -1,      /* bad argument (null pointer, non-positive size, unsupported combination) */
+    LVQ_EWORKSPACE = -2,  /* workspace too small */
+    LVQ_ELAUNCH = -3,     /* hipLaunch / runtime error (hipGetLastError != success) */
+    LVQ_EOVERFLOW = -4,   /* key space does not fit (e.g. batch * grid cells >= 2^31, see lvq_voxelize_dynamic) */
+    LVQ_EUNSUPPORTED = -5 /* shape outside what the kernels implement (documented per function) */
+};
+
+const char *lvq_version(void);
+const char *lvq_strerror(int code);
+/* number of exported entry points and their names (used by the "exports every symbol" test) */
+int lvq_abi_symbol_count(void);
+
+/* =====================================================================================
+ * LiDAR side
+ * ===================================================================================== */
+
+/* a1  pcdet/utils/common_utils.py:78-81 mask_points_by_range (via data_processor.py:79-93):
+ * keep[i] = lo_x <= x <= hi_x && lo_y <= y <= hi_y  (INCLUSIVE, z untested).
+ * pts [n,c] fp32 (x,y in columns 0,1); keep [n] uint8; range: host float[6]. */
+int lvq_mask_points_by_range(const float *pts, int64_t n, int c, const float *range_host, uint8_t *keep,
+                             lvq_stream_t stream);
+
+/* a3  data_processor.py:16-61,133-180  VoxelGeneratorWrapper.generate -> spconv Point2VoxelCPU3d
+ * (hard voxelisation), batched over scenes so that collate_batch (dataset.py:230-244, a4) is fused:
+ * outputs are the CONCATENATED per-scene results with the batch index already prepended.
+ *   pts            [n_points, c] fp32, scenes stored back to back; columns 0..2 = x,y,z
+ *   scene_off      [n_scenes+1] int32 point offsets (scene s owns points scene_off[s]..scene_off[s+1])
+ *   range/vsize/grid  host float[6] / float[3] / int32[3] (nx,ny,nz)
+ *   max_pts        T = MAX_POINTS_PER_VOXEL;   max_voxels = per-scene cap
+ *   break_on_cap   0 = spconv>=1.1/2.x `continue` semantics (default), 1 = spconv-1.0 `break`
+ *   voxel_capacity rows available in the three outputs; must be >= min(n_points, n_scenes*max_voxels)
+ *   voxels         [cap, T, c] fp32  (zero padded)
+ *   coords_bzyx    [cap, 4] int32    (batch, z, y, x)
+ *   num_pts        [cap] int32
+ *   scene_voxel_off[n_scenes+1] int32: scene s owns output rows [off[s], off[s+1]); off[n_scenes] = total M
+ * Voxel order inside a scene = first appearance in input order; the first T points of a voxel in
+ * input order are kept: bit-exact with the sequential CPU algorithm. */
+size_t lvq_voxelize_hard_workspace_bytes(int64_t n_points, int n_scenes);
+int lvq_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n_points, int n_scenes, int c,
+                      const float *range_host, const float *vsize_host, const int32_t *grid_host,
+                      int max_pts, int max_voxels, int break_on_cap, int64_t voxel_capacity,
+                      float *voxels, int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off,
+                      void *ws, size_t ws_bytes, lvq_stream_t stream);
+
+/* a5  backbones_3d/vfe/mean_vfe.py:25-29  MeanVFE.forward:
+ * out[m,:] = sum_t voxels[m,t,:] / max(num_pts[m],1).  n_voxels_dev (optional, may be NULL) points at
+ * a device int32 holding the live row count (<= m_cap), so the call needs no host sync. */
+int lvq_mean_vfe(const float *voxels, const int32_t *num_pts, int64_t m_cap, const int32_t *n_voxels_dev,
+                 int t, int c, float *out, lvq_stream_t stream);
+
+/* a6  backbones_3d/vfe/pillar_vfe.py:8-49,94-123  PillarVFE.forward + PFNLayer (eval BatchNorm folded
+ * into scale/shift by the caller: scale = gamma/sqrt(var+eps), shift = beta - mean*scale; with
+ * USE_NORM=False pass scale=1, shift=linear.bias).
+ *   voxels [m,T,c], num_pts [m], coords_bzyx [m,4]
+ *   n_layers PFN layers; layer l has weight w[l] [cout_l, cin_l] fp32 and scale/shift [cout_l];
+ *   w/scale/shift: HOST arrays of n_layers DEVICE pointers; cin/cout: host int arrays.
+ *   flags bit0 = USE_ABSLOTE_XYZ, bit1 = WITH_DISTANCE
+ *   voxel geometry: vsize[3], offset[3] = vsize/2 + range_lo  (host)
+ *   out [m, cout_last] fp32.   Limits: T <= 64, every cin/cout <= 256 (else LVQ_EUNSUPPORTED). */
+int lvq_pillar_vfe(const float *voxels, const int32_t *num_pts, const int32_t *coords_bzyx, int64_t m_cap,
+                   const int32_t *n_voxels_dev, int t, int c, int n_layers, const float *const *w_host,
+                   const float *const *scale_host, const float *const *shift_host, const int32_t *cin_host,
+                   const int32_t *cout_host, int flags, const float *vsize_host, const float *offset_host,
+                   float *out, lvq_stream_t stream);
+
+/* a7  backbones_3d/vfe/dynamic_mean_vfe.py:53-64, dynamic_pillar_vfe.py:93-103,
+ *     dynamic_voxel_vfe.py:60-71: floor((xyz-lo)/vs).int(), range mask, int32 linear key,
+ *     torch.unique(sorted, return_inverse, return_counts), key decode -> (b,z,y,x).
+ *   pts        [n, c] fp32, column 0 = batch index, 1..3 = x,y,z   (c >= 4)
+ *   ndim       3: key = b*nx*ny*nz + cx*ny*nz + cy*nz + cz ; 2: key = b*nx*ny + cx*ny + cy (z untested)
+ *   batch_size number of scenes (keys must stay below 2^31: else LVQ_EOVERFLOW -- the reference
+ *              silently wraps int32 there; that quirk is NOT reproduced)
+ *   unq_inv    [n] int32: rank of the point's voxel among the unique keys (ascending = torch.unique
+ *              order), -1 for points outside the grid (the reference drops them)
+ *   pt_coords  [n,3] int32 (cx,cy,cz) or NULL
+ *   unq_key    [cap] int32, unq_cnt [cap] int32, coords_bzyx [cap,4] int32,  cap >= min(n, key space)
+ *   counts     [2] int32: counts[0] = M unique voxels, counts[1] = N' valid points */
+size_t lvq_voxelize_dynamic_workspace_bytes(int64_t n_points, int batch_size, const int32_t *grid_host, int ndim);
+int lvq_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_size, const float *range_host,
+                         const float *vsize_host, const int32_t *grid_host, int ndim, int32_t *unq_inv,
+                         int32_t *pt_coords, int32_t *unq_key, int32_t *unq_cnt, int32_t *coords_bzyx,
+                         int32_t *counts, void *ws, size_t ws_bytes, lvq_stream_t stream);
+
+/* torch_scatter.scatter_mean(points[:,col0:col0+nc], unq_inv) as used by DynamicMeanVFE
+ * (dynamic_mean_vfe.py:64) and for points_mean in the PFN variants (dynamic_pillar_vfe.py:105).
+ * sums [m_cap,nc] must be zero on entry; on exit out = sums / max(cnt,1) (out may alias sums). */
+int lvq_scatter_mean(const float *pts, int64_t n, int c, int col0, int nc, const int32_t *unq_inv,
+                     const int32_t *unq_cnt, int64_t m_cap, float *sums, float *out, lvq_stream_t stream);
+
+/* a7  DynamicPillarVFE / DynamicVoxelVFE / DynamicPillarVFESimple2D forward after the unique step
+ * (dynamic_pillar_vfe.py:105-127,210-227; dynamic_voxel_vfe.py:73-92) with PFNLayerV2
+ * (dynamic_pillar_vfe.py:35-46), BatchNorm folded as in lvq_pillar_vfe.
+ *   kind 0 = pillar (f_center z = z - z_offset), 1 = voxel (per-cell z centre), 2 = simple2d (no f_cluster)
+ *   points_mean [m,3] from lvq_scatter_mean (ignored for kind 2)
+ *   n_layers <= 2; layer outputs cout_l <= 256.  xmax_tmp [m_cap, cout_0/1] scratch for 2-layer nets
+ *   (zero on entry), out [m_cap, cout_last] zero on entry (post-ReLU maxima are >= 0). */
+int lvq_dynamic_pfn(const float *pts, int64_t n, int c, const int32_t *unq_inv, const int32_t *pt_coords,
+                    const float *points_mean, int kind, int n_layers, const float *const *w_host,
+                    const float *const *scale_host, const float *const *shift_host, const int32_t *cin_host,
+                    const int32_t *cout_host, int flags, const float *vsize_host, const float *offset_host,
+                    float *xmax_tmp, float *out, lvq_stream_t stream);
+
+/* a8  backbones_2d/map_to_bev/pointpillar_scatter.py:14-37  PointPillarScatter.forward:
+ * canvas[b, ch, y, x] = feat[m, ch] for coords (b, z, y, x) with nz == 1; canvas is zero-filled here. */
+int lvq_pillar_scatter(const float *feat, const int32_t *coords_bzyx, int64_t m_cap, const int32_t *n_voxels_dev,
+                       int ch, int batch, int ny, int nx, float *canvas, lvq_stream_t stream);
+
+/* =====================================================================================
+ * Fusion side (VATBlock / VATLiDAR / VATVision / VisionAdapter building blocks)
+ * ===================================================================================== */
+
+/* nn.LayerNorm over the last dim (eps 1e-5 in every reference use: vat_blocks.py:19,23,27,
+ * vat_lidar.py:89,114,116, vision_adapter.py:56).  x [rows,d] fp32 (+ optional per-row-group
+ * additive embedding: x[r,:] + add[(r / add_group) % add_rows, :] BEFORE the norm -- VisionAdapter's
+ * `t + view_embed[v]`, vision_adapter.py:122).  Writes y_f32 and/or y_bf16 (either may be NULL). */
+int lvq_layernorm(const float *x, const float *add, int add_rows, int add_group, const float *gamma,
+                  const float *beta, float eps, int64_t rows, int d, float *y_f32, lvq_bf16 *y_bf16,
+                  lvq_stream_t stream);
+
+/* Linear layer on MFMA bf16 tiles with fp32 accumulation (nn.Linear / 1x1 Conv2d / MHA in_proj,
+ * out_proj; vat_blocks.py:28-34, vat_lidar.py:88,93-97,117-120, vat_vision.py:118-137,
+ * build_linear.py:18-19):
+ *   C[m, n] = epi( sum_k A[m,k] * W[n,k] + bias[n] )                    A [M,K] bf16, W [N,K] bf16
+ *   epi: flags & LVQ_GEMM_GELU -> exact erf GELU;  then * alpha;
+ *        + residual[m,n] (fp32 [M,N]) if residual != NULL;
+ *        + rowtab[(m % rowtab_rows), n] (fp32) if rowtab != NULL (input-independent positional tables:
+ *          geo_pe + view_embed[sid] of vat_lidar.py:235-248)
+ *   outputs: c_f32 [M,N] and/or c_bf16 [M,N] (either may be NULL).
+ *   precision: 1 = plain bf16 operands; 3 = split-bf16 (A and W each given as hi + lo parts:
+ *   a_lo / w_lo non-NULL; computes hi*hi + hi*lo + lo*hi, ~fp32-accurate products on bf16 MFMA). */
+enum { LVQ_GEMM_GELU = 1 };
+int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo,
+                  const float *bias, const float *residual, const float *rowtab, int64_t rowtab_rows,
+                  float alpha, int flags, int64_t m, int n, int k, float *c_f32, lvq_bf16 *c_bf16,
+                  lvq_stream_t stream);
+
+/* fp32 -> bf16 (round-to-nearest-even) with optional lo part (x - bf16(x)) for the split mode. */
+int lvq_cast_bf16(const float *x, int64_t n, lvq_bf16 *hi, lvq_bf16 *lo, lvq_stream_t stream);
+
+/* Attention core = F.scaled_dot_product_attention inside nn.MultiheadAttention (vat_blocks.py:39,42)
+ * and deepencoder sdp_attention (clip_sdpa.py:50-66, sam_vary_sdpa.py:27-42):
+ *   O[b,i,h,:] = softmax_j( Q[b,i,h,:].K[b,j,h,:] * scale + bias[b,h,i,j] ) V[b,j,h,:]
+ *   q [B,Nq,*] rows of stride ldq elements, head h at column offset h*dh (same for k, v, o), so packed
+ *   [B,N,3d] in_proj outputs and [B,H,S,D] tensors are both addressable without a copy:
+ *   q element (b,i,h,e) at q[(b*q_bstride) + i*ldq + h*q_hstride + e].
+ *   bias (optional, fp32 [B,H,Nq,Nkv]) ; causal != 0 adds the lower-triangular mask aligned to the END
+ *   (query i sees keys j <= i + Nkv - Nq), used by the stand-in decoder head.
+ *   n_kv_heads < n_heads => grouped-query attention (head h reads kv head h / (n_heads/n_kv_heads)).
+ *   Online softmax, statistics and accumulation in fp32; dh any multiple of 16 up to 1024. */
+int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *k, const lvq_bf16 *v, const float *bias,
+                       int batch, int n_heads, int n_kv_heads, int nq, int nkv, int dh,
+                       int64_t q_bstride, int64_t ldq, int64_t q_hstride,
+                       int64_t k_bstride, int64_t ldk, int64_t k_hstride,
+                       int64_t v_bstride, int64_t ldv, int64_t v_hstride,
+                       int64_t o_bstride, int64_t ldo, int64_t o_hstride,
+                       float scale, int causal, lvq_bf16 *o, lvq_stream_t stream);
+
+/* VATLiDAR front (vat_lidar.py:82-85,212): depthwise Conv2d(C,C,3,pad=1,groups=C) + exact GELU on
+ * NCHW fp32 input, written TOKEN-MAJOR [B, H*W, C] as bf16 (the A operand of the 1x1-conv GEMM). */
+int lvq_dwconv3x3_gelu(const float *bev, const float *w9, const float *bias, int batch, int ch, int h, int w,
+                       lvq_bf16 *tokens_hi, lvq_bf16 *tokens_lo, lvq_stream_t stream);
+
+/* out[r, :] = x[r, :] * alpha + add[(r % add_rows), :]  (query = query + view_embed chunk,
+ * vat_lidar.py:259-270; prefix * prefix_scale, trainer.py:581,594) -- fp32 elementwise. */
+int lvq_scale_add_rows(const float *x, const float *add, int64_t add_rows, float alpha, int64_t rows, int d,
+                       float *out, lvq_stream_t stream);
+
+/* Stand-in decoder head pieces (Qwen2-style; validation.py:146-156 drives `base(inputs_embeds, labels)`):
+ * RMSNorm, rotary embedding applied in place to packed q|k projections, SiLU(gate)*up. */
+int lvq_rmsnorm(const float *x, const float *gamma, float eps, int64_t rows, int d, float *y_f32, lvq_bf16 *y_bf16,
+                lvq_bf16 *y_lo, lvq_stream_t stream);
+int lvq_rope_inplace(lvq_bf16 *x, int64_t rows, int seq_len, int n_heads, int dh, int64_t ld, float theta,
+                     lvq_stream_t stream);
+int lvq_swiglu(const float *gate_up, int64_t rows, int inter, lvq_bf16 *out_hi, lvq_bf16 *out_lo, lvq_stream_t stream);
+/* mean shifted cross-entropy over labels != -100 (transformers causal-LM loss): logits [rows,vocab] fp32,
+ * labels [rows] int64 already shifted by the caller; loss_sum_cnt [2] fp32 accumulators (zero on entry). */
+int lvq_cross_entropy(const float *logits, const int64_t *labels, int64_t rows, int vocab, float *loss_sum_cnt,
+                      lvq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVQ_H */

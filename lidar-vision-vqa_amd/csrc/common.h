@@ -1,0 +1,50 @@
+// csrc/common.h -- shared helpers for the gfx950 kernels behind include/lvq.h
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/lvq.h"
+
+#define LVQ_WAVE 64
+
+static inline hipStream_t lvq_s(lvq_stream_t s) { return (hipStream_t)s; }
+
+// every entry point ends with this: launch errors become a return code, never an abort
+static inline int lvq_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LVQ_OK : LVQ_ELAUNCH;
+}
+
+static inline int64_t lvq_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t lvq_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// bump allocator over the caller's workspace
+struct LvqArena {
+    char *base;
+    size_t off, cap;
+    bool ok;
+    LvqArena(void *p, size_t bytes) : base((char *)p), off(0), cap(bytes), ok(true) {}
+    template <typename T> T *take(size_t n) {
+        size_t o = lvq_align(off);
+        size_t e = o + n * sizeof(T);
+        if (base == nullptr || e > cap) { ok = false; off = e; return nullptr; }
+        off = e;
+        return (T *)(base + o);
+    }
+};
+// same arithmetic without memory, for *_workspace_bytes
+struct LvqSizer {
+    size_t off = 0;
+    template <typename T> void take(size_t n) { off = lvq_align(off) + n * sizeof(T); }
+    size_t total() const { return lvq_align(off) + 256; }
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// round-to-nearest-even fp32 -> bf16; NaN stays NaN (MI355X_MICROARCH "Correctness boundaries")
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

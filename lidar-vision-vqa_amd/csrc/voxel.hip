@@ -1,0 +1,635 @@
+// csrc/voxel.hip -- point cloud -> voxel index kernels (HBM-bound integer work, gfx950).
+//
+//   lvq_mask_points_by_range   a1  pcdet/utils/common_utils.py:78-81
+//   lvq_voxelize_hard          a3  data_processor.py:16-61,133-180 (spconv Point2VoxelCPU3d semantics)
+//                              + a4 collate_batch (dataset.py:230-244) fused: batched, batch index prepended
+//   lvq_voxelize_dynamic       a7  dynamic_mean_vfe.py:53-71 / dynamic_pillar_vfe.py:93-135 /
+//                                  dynamic_voxel_vfe.py:60-101 (floor/mask/key/torch.unique/decode)
+//
+// Design (MI355X-first, not a translation of spconv's sequential dense-table loop):
+//   * hard: an open-addressing hash over (scene, cell) keys records, with atomicMin, the FIRST point
+//     index of every occupied cell.  "voxel id = first-appearance order" is then the rank of that first
+//     index among all first indices = a prefix popcount over a 1-bit-per-point mask (64 points per
+//     word, one ballot per wave) -- a 4 KB scan for a 32k-point scene instead of a sort.  "first T points
+//     in input order" = each point counts the smaller indices in its voxel's bucket (contiguous,
+//     L2-resident) and stops at T.  Everything is order-independent => bit-exact with the sequential
+//     algorithm, including the max_voxels cap in both its `continue` and `break` variants.
+//   * dynamic: torch.unique's ascending-key order is produced without a sort by a two-level bitmap:
+//     level 1 marks occupied 64-key words, a popcount scan compacts them, level 0 holds the 64-bit
+//     occupancy of each occupied word, a second popcount scan ranks the keys.  Traffic ~ O(points)
+//     + keyspace/4096 bytes, instead of radix-sort passes.
+//   * all scans are popcount scans of u64 words (single-workgroup for <= 32k words, 3-kernel otherwise).
+//   * divisions are IEEE fp32 (-fhip-fp32-correctly-rounded-divide-sqrt, no fast-math) so that
+//     floor((p - lo) / vs) matches the CPU bit for bit.
+#include "common.h"
+
+namespace {
+
+struct Geom {
+    float lo[3];
+    float vs[3];
+    int grid[3];
+};
+
+__device__ __forceinline__ bool cell_of(const float *p, const Geom &g, int ndim, int cc[3]) {
+    bool ok = true;
+    cc[0] = cc[1] = cc[2] = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j < ndim) {
+            float d = p[j] - g.lo[j];
+            float q = d / g.vs[j];
+            float f = floorf(q);
+            bool in = (f >= 0.0f) && (f < (float)g.grid[j]);  // NaN/inf fail here like (int) casts do on the CPU
+            ok = ok && in;
+            cc[j] = in ? (int)f : -1;
+        }
+    }
+    return ok;
+}
+
+__device__ __forceinline__ int find_scene(const int32_t *off, int n_scenes, int i) {
+    int lo = 0, hi = n_scenes;  // largest s with off[s] <= i
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t mix64(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return (uint32_t)k;
+}
+
+__device__ __forceinline__ int popc_below(uint64_t m, int bit) {
+    return __popcll(m & ((bit == 0) ? 0ull : (~0ull >> (64 - bit))));
+}
+
+// ---------------------------------------------------------------------------------------------
+// popcount scans
+// ---------------------------------------------------------------------------------------------
+// block-wide exclusive scan of one int per thread (blockDim.x multiple of 64, <= 1024)
+__device__ __forceinline__ int block_excl_scan(int v, int *lds_wave_tot, int &block_total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) lds_wave_tot[wid] = incl;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+    for (int w = 0; w < nw; ++w) {
+        int t = lds_wave_tot[w];
+        if (w < wid) wbase += t;
+        tot += t;
+    }
+    __syncthreads();
+    block_total = tot;
+    return wbase + incl - v;
+}
+
+// prefix[w] = sum_{u<w} popc(words[u]) for w in [0, nwords]; single workgroup, any length
+__global__ void __launch_bounds__(1024) k_scan_popc_single(const uint64_t *__restrict__ words, int64_t nwords,
+                                                            int32_t *__restrict__ prefix, int32_t *total_out) {
+    __shared__ int wave_tot[16];
+    int running = 0;
+    for (int64_t base = 0; base < nwords; base += 1024) {
+        int64_t w = base + threadIdx.x;
+        int v = (w < nwords) ? __popcll(words[w]) : 0;
+        int tot;
+        int ex = block_excl_scan(v, wave_tot, tot);
+        if (w < nwords) prefix[w] = running + ex;
+        running += tot;
+    }
+    if (threadIdx.x == 0) {
+        prefix[nwords] = running;
+        if (total_out) *total_out = running;
+    }
+}
+
+constexpr int SCAN_TILE = 4096;  // words per workgroup in the 3-kernel form (256 threads x 16)
+
+__global__ void __launch_bounds__(256) k_scan_popc_tilesum(const uint64_t *__restrict__ words, int64_t nwords,
+                                                           int32_t *__restrict__ tsum) {
+    __shared__ int wave_tot[4];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        int64_t w = base + j * 256 + threadIdx.x;
+        if (w < nwords) s += __popcll(words[w]);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tsum[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+// in-place exclusive scan of tile sums; tsum[nt] = total
+__global__ void __launch_bounds__(1024) k_scan_tiles(int32_t *tsum, int nt, int32_t *total_out) {
+    __shared__ int wave_tot[16];
+    int running = 0;
+    for (int base = 0; base < nt; base += 1024) {
+        int t = base + threadIdx.x;
+        int v = (t < nt) ? tsum[t] : 0;
+        int tot;
+        int ex = block_excl_scan(v, wave_tot, tot);
+        if (t < nt) tsum[t] = running + ex;
+        running += tot;
+    }
+    if (threadIdx.x == 0) {
+        tsum[nt] = running;
+        if (total_out) *total_out = running;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scan_popc_apply(const uint64_t *__restrict__ words, int64_t nwords,
+                                                         const int32_t *__restrict__ tsum, int nt,
+                                                         int32_t *__restrict__ prefix) {
+    __shared__ int wave_tot[4];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    int running = tsum[blockIdx.x];
+    // thread t owns words base + 16*t .. +15 (contiguous) so one block scan suffices
+    int v[16];
+    int s = 0;
+    int64_t w0 = base + (int64_t)threadIdx.x * 16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        int64_t w = w0 + j;
+        v[j] = (w < nwords) ? __popcll(words[w]) : 0;
+        s += v[j];
+    }
+    int tot;
+    int ex = block_excl_scan(s, wave_tot, tot) + running;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        int64_t w = w0 + j;
+        if (w < nwords) prefix[w] = ex;
+        ex += v[j];
+    }
+    if (blockIdx.x == nt - 1 && threadIdx.x == 0) prefix[nwords] = tsum[nt];
+}
+
+// prefix must hold nwords+1 ints, tsum ceil(nwords/SCAN_TILE)+1 ints
+void scan_popc(const uint64_t *words, int64_t nwords, int32_t *prefix, int32_t *tsum, int32_t *total_out,
+               hipStream_t st) {
+    if (nwords <= 32768) {
+        hipLaunchKernelGGL(k_scan_popc_single, dim3(1), dim3(1024), 0, st, words, nwords, prefix, total_out);
+        return;
+    }
+    int nt = (int)lvq_cdiv(nwords, SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_popc_tilesum, dim3(nt), dim3(256), 0, st, words, nwords, tsum);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tsum, nt, total_out);
+    hipLaunchKernelGGL(k_scan_popc_apply, dim3(nt), dim3(256), 0, st, words, nwords, tsum, nt, prefix);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a1 range mask
+// ---------------------------------------------------------------------------------------------
+__global__ void k_mask_range(const float *__restrict__ pts, int64_t n, int c, float lx, float ly, float hx, float hy,
+                             uint8_t *__restrict__ keep) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = pts[i * c], y = pts[i * c + 1];
+    keep[i] = (x >= lx) && (x <= hx) && (y >= ly) && (y <= hy);
+}
+
+// ---------------------------------------------------------------------------------------------
+// hard voxeliser
+// ---------------------------------------------------------------------------------------------
+constexpr uint64_t EMPTY_KEY = ~0ull;
+
+struct HardWs {
+    uint64_t *keys;    // [cap]   hash keys, EMPTY_KEY when free
+    int32_t *first;    // [cap]   smallest point index of the cell
+    int32_t *count;    // [cap]   points in the cell
+    int32_t *fill;     // [cap]   bucket fill cursor
+    int32_t *bstart;   // [cap]   bucket start
+    int32_t *vid;      // [cap]   output row of the cell's voxel or -1
+    int32_t *slot;     // [n]     hash slot of each point or -1
+    int32_t *bucket;   // [n]     point indices grouped by cell
+    uint64_t *fmask;   // [nwords+1] 1 bit per point: "is the first point of its cell"
+    int32_t *wprefix;  // [nwords+2]
+    int32_t *tsum;     // scan tiles
+    int32_t *sfr;      // [n_scenes+1] global first-rank at each scene start
+    int32_t *limit;    // [n_scenes]   `break` variant: first point index that is past the cap
+    int32_t *cursor;   // [1] bucket allocator
+};
+
+__global__ void k_hard_init(HardWs w, int64_t cap, int64_t nwords, int n_scenes) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = i; j < cap; j += stride) {
+        w.keys[j] = EMPTY_KEY;
+        w.first[j] = 0x7fffffff;
+        w.count[j] = 0;
+        w.fill[j] = 0;
+    }
+    for (int64_t j = i; j <= nwords; j += stride) w.fmask[j] = 0;
+    for (int64_t j = i; j < n_scenes; j += stride) w.limit[j] = 0x7fffffff;
+    if (i == 0) *w.cursor = 0;
+}
+
+template <int C4>
+__global__ void __launch_bounds__(256) k_hard_insert(const float *__restrict__ pts, const int32_t *__restrict__ scene_off,
+                                                     int n, int n_scenes, int c, Geom g, uint32_t cap_mask, HardWs w) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float p[3];
+    if (C4) {
+        float4 v = reinterpret_cast<const float4 *>(pts)[i];
+        p[0] = v.x; p[1] = v.y; p[2] = v.z;
+    } else {
+        p[0] = pts[(int64_t)i * c]; p[1] = pts[(int64_t)i * c + 1]; p[2] = pts[(int64_t)i * c + 2];
+    }
+    int cc[3];
+    if (!cell_of(p, g, 3, cc)) { w.slot[i] = -1; return; }
+    int s = find_scene(scene_off, n_scenes, i);
+    const uint64_t cells = (uint64_t)g.grid[0] * g.grid[1] * g.grid[2];
+    uint64_t key = (uint64_t)s * cells + ((uint64_t)cc[2] * g.grid[1] + cc[1]) * g.grid[0] + cc[0];
+    uint32_t h = mix64(key) & cap_mask;
+    for (;;) {
+        unsigned long long prev = atomicCAS((unsigned long long *)&w.keys[h], (unsigned long long)EMPTY_KEY,
+                                            (unsigned long long)key);
+        if (prev == EMPTY_KEY || prev == key) break;
+        h = (h + 1) & cap_mask;  // table is <= 50 % full: probing always ends
+    }
+    atomicMin(&w.first[h], i);
+    atomicAdd(&w.count[h], 1);
+    w.slot[i] = (int)h;
+}
+
+__global__ void __launch_bounds__(256) k_hard_flags(int n, HardWs w) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    int sl = (i < n) ? w.slot[i] : -1;
+    bool isf = (sl >= 0) && (w.first[sl] == i);
+    unsigned long long m = __ballot(isf);
+    if ((threadIdx.x & 63) == 0 && i < n) w.fmask[i >> 6] = m;
+    if (isf) w.bstart[sl] = atomicAdd(w.cursor, w.count[sl]);
+}
+
+__device__ __forceinline__ int first_rank(const HardWs &w, int i) {
+    return w.wprefix[i >> 6] + popc_below(w.fmask[i >> 6], i & 63);
+}
+
+// per scene: global rank at scene start, voxel totals, packed output offsets
+__global__ void k_hard_scene_offsets(const int32_t *__restrict__ scene_off, int n_scenes, int max_voxels, HardWs w,
+                                     int32_t *__restrict__ scene_voxel_off) {
+    for (int s = threadIdx.x; s <= n_scenes; s += blockDim.x) w.sfr[s] = first_rank(w, scene_off[s]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int s = 0; s < n_scenes; ++s) {
+            scene_voxel_off[s] = acc;
+            int tot = w.sfr[s + 1] - w.sfr[s];
+            acc += tot < max_voxels ? tot : max_voxels;
+        }
+        scene_voxel_off[n_scenes] = acc;
+    }
+}
+
+template <int C4>
+__global__ void __launch_bounds__(256) k_hard_assign(const float *__restrict__ pts, const int32_t *__restrict__ scene_off,
+                                                     int n, int n_scenes, int c, Geom g, int max_voxels, HardWs w,
+                                                     const int32_t *__restrict__ scene_voxel_off,
+                                                     int32_t *__restrict__ coords_bzyx) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int sl = w.slot[i];
+    if (sl < 0) return;
+    if (w.first[sl] == i) {
+        int s = find_scene(scene_off, n_scenes, i);
+        int r = first_rank(w, i) - w.sfr[s];
+        if (r < max_voxels) {
+            int v = scene_voxel_off[s] + r;
+            w.vid[sl] = v;
+            float p[3];
+            if (C4) {
+                float4 q = reinterpret_cast<const float4 *>(pts)[i];
+                p[0] = q.x; p[1] = q.y; p[2] = q.z;
+            } else {
+                p[0] = pts[(int64_t)i * c]; p[1] = pts[(int64_t)i * c + 1]; p[2] = pts[(int64_t)i * c + 2];
+            }
+            int cc[3];
+            cell_of(p, g, 3, cc);
+            reinterpret_cast<int4 *>(coords_bzyx)[v] = make_int4(s, cc[2], cc[1], cc[0]);
+        } else {
+            w.vid[sl] = -1;
+            if (r == max_voxels) w.limit[s] = i;
+        }
+    }
+    int pos = w.bstart[sl] + atomicAdd(&w.fill[sl], 1);
+    w.bucket[pos] = i;
+}
+
+template <int C4>
+__global__ void __launch_bounds__(256) k_hard_write(const float *__restrict__ pts, const int32_t *__restrict__ scene_off,
+                                                    int n, int n_scenes, int c, int T, int break_on_cap, HardWs w,
+                                                    float *__restrict__ voxels, int32_t *__restrict__ num_pts) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int sl = w.slot[i];
+    if (sl < 0) return;
+    int v = w.vid[sl];
+    if (v < 0) return;
+    int lim = 0x7fffffff;
+    if (break_on_cap) lim = w.limit[find_scene(scene_off, n_scenes, i)];
+    if (i >= lim) return;
+    const int cnt = w.count[sl];
+    const bool isf = (w.first[sl] == i);
+    int r = 0, tot = cnt;
+    if (cnt > 1) {
+        const int32_t *b = w.bucket + w.bstart[sl];
+        tot = 0;
+        for (int j = 0; j < cnt; ++j) {
+            int idx = b[j];
+            r += (idx < i);
+            tot += (idx < lim);
+            if (!isf && r >= T) break;
+        }
+    }
+    if (r < T) {
+        float *dst = voxels + ((int64_t)v * T + r) * c;
+        if (C4) {
+            reinterpret_cast<float4 *>(dst)[0] = reinterpret_cast<const float4 *>(pts)[i];
+        } else {
+            for (int k = 0; k < c; ++k) dst[k] = pts[(int64_t)i * c + k];
+        }
+    }
+    if (isf) {
+        int np = tot < T ? tot : T;
+        num_pts[v] = np;
+        float *dst = voxels + ((int64_t)v * T + np) * c;
+        int nz = (T - np) * c;
+        if (C4) {
+            for (int k = 0; k < T - np; ++k) reinterpret_cast<float4 *>(dst)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (int k = 0; k < nz; ++k) dst[k] = 0.f;
+        }
+    }
+}
+
+uint32_t hard_cap(int64_t n) {
+    uint64_t cap = 1024;
+    while (cap < (uint64_t)n * 2) cap <<= 1;
+    return (uint32_t)cap;
+}
+
+template <typename A> void hard_layout(A &a, HardWs &w, int64_t n, int n_scenes) {
+    const int64_t cap = hard_cap(n);
+    const int64_t nwords = lvq_cdiv(n, 64);
+    w.keys = a.template take<uint64_t>(cap);
+    w.first = a.template take<int32_t>(cap);
+    w.count = a.template take<int32_t>(cap);
+    w.fill = a.template take<int32_t>(cap);
+    w.bstart = a.template take<int32_t>(cap);
+    w.vid = a.template take<int32_t>(cap);
+    w.slot = a.template take<int32_t>(n);
+    w.bucket = a.template take<int32_t>(n);
+    w.fmask = a.template take<uint64_t>(nwords + 1);
+    w.wprefix = a.template take<int32_t>(nwords + 2);
+    w.tsum = a.template take<int32_t>(lvq_cdiv(nwords + 1, SCAN_TILE) + 2);
+    w.sfr = a.template take<int32_t>(n_scenes + 1);
+    w.limit = a.template take<int32_t>(n_scenes);
+    w.cursor = a.template take<int32_t>(4);
+}
+
+struct SizerAdapter {
+    LvqSizer s;
+    template <typename T> T *take(size_t n) { s.template take<T>(n); return nullptr; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// dynamic voxeliser
+// ---------------------------------------------------------------------------------------------
+struct DynWs {
+    uint64_t *l1;      // [n1]   bit per 64-key word
+    int32_t *l1pre;    // [n1+1]
+    uint64_t *l0;      // [n+1]  compact occupancy words (<= one per valid point)
+    int32_t *l0pre;    // [n+2]
+    int32_t *key;      // [n]    linear key or -1
+    int32_t *wrank;    // [n]    compact word index
+    int32_t *tsum;
+    int32_t *nwords_c; // [1] number of compact words (unused by the host)
+};
+
+template <typename A> void dyn_layout(A &a, DynWs &w, int64_t n, int64_t keyspace) {
+    const int64_t n0 = lvq_cdiv(keyspace, 64);
+    const int64_t n1 = lvq_cdiv(n0, 64);
+    w.l1 = a.template take<uint64_t>(n1 + 1);
+    w.l1pre = a.template take<int32_t>(n1 + 2);
+    w.l0 = a.template take<uint64_t>(n + 1);
+    w.l0pre = a.template take<int32_t>(n + 2);
+    w.key = a.template take<int32_t>(n);
+    w.wrank = a.template take<int32_t>(n);
+    int64_t big = n1 > n ? n1 : n;
+    w.tsum = a.template take<int32_t>(lvq_cdiv(big + 1, SCAN_TILE) + 2);
+    w.nwords_c = a.template take<int32_t>(4);
+}
+
+__global__ void k_dyn_init(DynWs w, int64_t n1, int64_t n, int32_t *unq_cnt, int64_t cap, int32_t *counts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = i; j <= n1; j += stride) w.l1[j] = 0;
+    for (int64_t j = i; j <= n; j += stride) w.l0[j] = 0;
+    for (int64_t j = i; j < cap; j += stride) unq_cnt[j] = 0;
+    if (i == 0) { counts[0] = 0; counts[1] = 0; }
+}
+
+__global__ void __launch_bounds__(256) k_dyn_keys(const float *__restrict__ pts, int n, int c, Geom g, int ndim,
+                                                  int batch_size, DynWs w, int32_t *__restrict__ pt_coords, int32_t *__restrict__ unq_inv,
+                                                  int32_t *__restrict__ counts) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    bool ok = false;
+    if (i < n) {
+        const float *p = pts + (int64_t)i * c;
+        float xyz[3] = {p[1], p[2], p[3]};
+        int cc[3];
+        ok = cell_of(xyz, g, ndim, cc);
+        if (pt_coords) { pt_coords[i * 3] = cc[0]; pt_coords[i * 3 + 1] = cc[1]; pt_coords[i * 3 + 2] = cc[2]; }
+        int key = -1;
+        const int b = (int)p[0];
+        ok = ok && (b >= 0) && (b < batch_size);   // a batch index outside [0,batch_size) would leave the key space
+        if (ok) {
+            if (ndim == 3) key = ((b * g.grid[0] + cc[0]) * g.grid[1] + cc[1]) * g.grid[2] + cc[2];
+            else           key = (b * g.grid[0] + cc[0]) * g.grid[1] + cc[1];
+            uint32_t wd = (uint32_t)key >> 6;
+            atomicOr((unsigned long long *)&w.l1[wd >> 6], 1ull << (wd & 63));
+        } else {
+            unq_inv[i] = -1;
+        }
+        w.key[i] = key;
+    }
+    unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counts[1], __popcll(m));
+}
+
+__global__ void __launch_bounds__(256) k_dyn_words(int n, DynWs w) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int key = w.key[i];
+    if (key < 0) return;
+    uint32_t wd = (uint32_t)key >> 6;
+    int wr = w.l1pre[wd >> 6] + popc_below(w.l1[wd >> 6], wd & 63);
+    w.wrank[i] = wr;
+    atomicOr((unsigned long long *)&w.l0[wr], 1ull << (key & 63));
+}
+
+__global__ void __launch_bounds__(256) k_dyn_rank(int n, Geom g, int ndim, DynWs w, int32_t *__restrict__ unq_inv,
+                                                  int32_t *__restrict__ unq_key, int32_t *__restrict__ unq_cnt,
+                                                  int32_t *__restrict__ coords_bzyx) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int key = w.key[i];
+    if (key < 0) return;
+    int wr = w.wrank[i];
+    int vr = w.l0pre[wr] + popc_below(w.l0[wr], key & 63);
+    unq_inv[i] = vr;
+    int old = atomicAdd(&unq_cnt[vr], 1);
+    if (old == 0) {
+        unq_key[vr] = key;
+        int b, cx, cy, cz;
+        if (ndim == 3) {
+            cz = key % g.grid[2]; int t = key / g.grid[2];
+            cy = t % g.grid[1]; t /= g.grid[1];
+            cx = t % g.grid[0]; b = t / g.grid[0];
+        } else {
+            cz = 0;
+            cy = key % g.grid[1]; int t = key / g.grid[1];
+            cx = t % g.grid[0]; b = t / g.grid[0];
+        }
+        reinterpret_cast<int4 *>(coords_bzyx)[vr] = make_int4(b, cz, cy, cx);
+    }
+}
+
+}  // namespace
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" int lvq_mask_points_by_range(const float *pts, int64_t n, int c, const float *range_host, uint8_t *keep,
+                                        lvq_stream_t stream) {
+    if (n < 0 || c < 2 || !range_host || (n > 0 && (!pts || !keep))) return LVQ_EINVAL;
+    if (n == 0) return LVQ_OK;
+    hipLaunchKernelGGL(k_mask_range, dim3((unsigned)lvq_cdiv(n, 256)), dim3(256), 0, lvq_s(stream), pts, n, c,
+                       range_host[0], range_host[1], range_host[3], range_host[4], keep);
+    return lvq_launch_status();
+}
+
+extern "C" size_t lvq_voxelize_hard_workspace_bytes(int64_t n_points, int n_scenes) {
+    if (n_points < 0 || n_scenes < 0) return 0;
+    SizerAdapter a;
+    HardWs w;
+    hard_layout(a, w, n_points, n_scenes);
+    return a.s.total();
+}
+
+extern "C" int lvq_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n_points, int n_scenes, int c,
+                                 const float *range_host, const float *vsize_host, const int32_t *grid_host,
+                                 int max_pts, int max_voxels, int break_on_cap, int64_t voxel_capacity,
+                                 float *voxels, int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off,
+                                 void *ws, size_t ws_bytes, lvq_stream_t stream) {
+    if (n_points < 0 || n_scenes <= 0 || c < 3 || max_pts <= 0 || max_voxels <= 0 || !range_host || !vsize_host ||
+        !grid_host || !scene_off || !scene_voxel_off)
+        return LVQ_EINVAL;
+    if (n_points >= (1ll << 30)) return LVQ_EUNSUPPORTED;
+    for (int j = 0; j < 3; ++j)
+        if (grid_host[j] <= 0 || !(vsize_host[j] > 0.f)) return LVQ_EINVAL;
+    hipStream_t st = lvq_s(stream);
+    if (n_points == 0) {
+        hipMemsetAsync(scene_voxel_off, 0, sizeof(int32_t) * (n_scenes + 1), st);
+        return lvq_launch_status();
+    }
+    int64_t need = n_points < (int64_t)n_scenes * max_voxels ? n_points : (int64_t)n_scenes * max_voxels;
+    if (voxel_capacity < need || !pts || !voxels || !coords_bzyx || !num_pts) return LVQ_EINVAL;
+    LvqArena arena(ws, ws_bytes);
+    HardWs w;
+    hard_layout(arena, w, n_points, n_scenes);
+    if (!arena.ok) return LVQ_EWORKSPACE;
+    Geom g;
+    for (int j = 0; j < 3; ++j) { g.lo[j] = range_host[j]; g.vs[j] = vsize_host[j]; g.grid[j] = grid_host[j]; }
+    const int n = (int)n_points;
+    const uint32_t cap = hard_cap(n_points);
+    const int64_t nwords = lvq_cdiv(n_points, 64);
+    const unsigned nb = (unsigned)lvq_cdiv(n_points, 256);
+    const bool c4 = (c == 4) && (((uintptr_t)pts & 15) == 0) && (((uintptr_t)voxels & 15) == 0);
+    hipLaunchKernelGGL(k_hard_init, dim3((unsigned)(cap / 256 < 2048 ? cap / 256 : 2048)), dim3(256), 0, st, w,
+                       (int64_t)cap, nwords, n_scenes);
+    if (c4) hipLaunchKernelGGL(k_hard_insert<1>, dim3(nb), dim3(256), 0, st, pts, scene_off, n, n_scenes, c, g, cap - 1, w);
+    else    hipLaunchKernelGGL(k_hard_insert<0>, dim3(nb), dim3(256), 0, st, pts, scene_off, n, n_scenes, c, g, cap - 1, w);
+    hipLaunchKernelGGL(k_hard_flags, dim3(nb), dim3(256), 0, st, n, w);
+    scan_popc(w.fmask, nwords + 1, w.wprefix, w.tsum, nullptr, st);
+    hipLaunchKernelGGL(k_hard_scene_offsets, dim3(1), dim3(256), 0, st, scene_off, n_scenes, max_voxels, w,
+                       scene_voxel_off);
+    if (c4) {
+        hipLaunchKernelGGL(k_hard_assign<1>, dim3(nb), dim3(256), 0, st, pts, scene_off, n, n_scenes, c, g, max_voxels, w,
+                           scene_voxel_off, coords_bzyx);
+        hipLaunchKernelGGL(k_hard_write<1>, dim3(nb), dim3(256), 0, st, pts, scene_off, n, n_scenes, c, max_pts,
+                           break_on_cap, w, voxels, num_pts);
+    } else {
+        hipLaunchKernelGGL(k_hard_assign<0>, dim3(nb), dim3(256), 0, st, pts, scene_off, n, n_scenes, c, g, max_voxels, w,
+                           scene_voxel_off, coords_bzyx);
+        hipLaunchKernelGGL(k_hard_write<0>, dim3(nb), dim3(256), 0, st, pts, scene_off, n, n_scenes, c, max_pts,
+                           break_on_cap, w, voxels, num_pts);
+    }
+    return lvq_launch_status();
+}
+
+static int64_t dyn_keyspace(int batch_size, const int32_t *grid, int ndim) {
+    int64_t ks = (int64_t)batch_size * grid[0] * grid[1];
+    if (ndim == 3) ks *= grid[2];
+    return ks;
+}
+
+extern "C" size_t lvq_voxelize_dynamic_workspace_bytes(int64_t n_points, int batch_size, const int32_t *grid_host,
+                                                       int ndim) {
+    if (n_points < 0 || batch_size <= 0 || !grid_host || (ndim != 2 && ndim != 3)) return 0;
+    int64_t ks = dyn_keyspace(batch_size, grid_host, ndim);
+    if (ks >= (1ll << 31)) return 0;
+    SizerAdapter a;
+    DynWs w;
+    dyn_layout(a, w, n_points, ks);
+    return a.s.total();
+}
+
+extern "C" int lvq_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_size, const float *range_host,
+                                    const float *vsize_host, const int32_t *grid_host, int ndim, int32_t *unq_inv,
+                                    int32_t *pt_coords, int32_t *unq_key, int32_t *unq_cnt, int32_t *coords_bzyx,
+                                    int32_t *counts, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+    if (n < 0 || c < 4 || batch_size <= 0 || !range_host || !vsize_host || !grid_host || (ndim != 2 && ndim != 3) ||
+        !counts)
+        return LVQ_EINVAL;
+    for (int j = 0; j < ndim; ++j)
+        if (grid_host[j] <= 0 || !(vsize_host[j] > 0.f)) return LVQ_EINVAL;
+    if (n >= (1ll << 30)) return LVQ_EUNSUPPORTED;
+    const int64_t ks = dyn_keyspace(batch_size, grid_host, ndim);
+    if (ks >= (1ll << 31)) return LVQ_EOVERFLOW;
+    hipStream_t st = lvq_s(stream);
+    if (n == 0) {
+        hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st);
+        return lvq_launch_status();
+    }
+    if (!pts || !unq_inv || !unq_key || !unq_cnt || !coords_bzyx) return LVQ_EINVAL;
+    LvqArena arena(ws, ws_bytes);
+    DynWs w;
+    dyn_layout(arena, w, n, ks);
+    if (!arena.ok) return LVQ_EWORKSPACE;
+    Geom g;
+    for (int j = 0; j < 3; ++j) { g.lo[j] = range_host[j]; g.vs[j] = vsize_host[j]; g.grid[j] = grid_host[j]; }
+    const int64_t n0 = lvq_cdiv(ks, 64), n1 = lvq_cdiv(n0, 64);
+    const int64_t cap = n < ks ? n : ks;
+    const unsigned nb = (unsigned)lvq_cdiv(n, 256);
+    int64_t initn = (n1 > n ? n1 : n) + 1;
+    unsigned ib = (unsigned)(lvq_cdiv(initn, 256) < 2048 ? lvq_cdiv(initn, 256) : 2048);
+    hipLaunchKernelGGL(k_dyn_init, dim3(ib), dim3(256), 0, st, w, n1, n, unq_cnt, cap, counts);
+    hipLaunchKernelGGL(k_dyn_keys, dim3(nb), dim3(256), 0, st, pts, (int)n, c, g, ndim, batch_size, w, pt_coords, unq_inv,
+                       counts);
+    scan_popc(w.l1, n1 + 1, w.l1pre, w.tsum, w.nwords_c, st);
+    hipLaunchKernelGGL(k_dyn_words, dim3(nb), dim3(256), 0, st, (int)n, w);
+    scan_popc(w.l0, n + 1, w.l0pre, w.tsum, &counts[0], st);
+    hipLaunchKernelGGL(k_dyn_rank, dim3(nb), dim3(256), 0, st, (int)n, g, ndim, w, unq_inv, unq_key, unq_cnt, coords_bzyx);
+    return lvq_launch_status();
+}
