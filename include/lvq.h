@@ -42,8 +42,6 @@ enum {
 
 const char *lvq_version(void);
 const char *lvq_strerror(int code);
-/* number of exported entry points and their names (used by the "exports every symbol" test) */
-int lvq_abi_symbol_count(void);
 
 /* =====================================================================================
  * LiDAR side
@@ -144,51 +142,62 @@ int lvq_pillar_scatter(const float *feat, const int32_t *coords_bzyx, int64_t m_
  * Fusion side (VATBlock / VATLiDAR / VATVision / VisionAdapter building blocks)
  * ===================================================================================== */
 
+/* Precision modes of the fusion kernels.  Accumulation, LayerNorm / softmax statistics and residuals
+ * are always fp32.  Every bf16 tensor may travel as ONE array (plain bf16 operands, "bf16") or as a
+ * hi + lo PAIR (x = hi + lo to ~2^-17, "bf16x3": products are formed as hi*hi + hi*lo + lo*hi on the same
+ * bf16 MFMA tiles).  Passing the `_lo` pointers selects the mode per call; producers write the lo twin
+ * when its pointer is non-NULL.  bf16x3 is the mode that meets the 1e-3 parity bar against the fp32 CPU
+ * path (plain bf16 operand rounding alone is ~2e-3 of max|out|; see DESIGN.md "Numerics"). */
+
 /* nn.LayerNorm over the last dim (eps 1e-5 in every reference use: vat_blocks.py:19,23,27,
  * vat_lidar.py:89,114,116, vision_adapter.py:56).  x [rows,d] fp32 (+ optional per-row-group
  * additive embedding: x[r,:] + add[(r / add_group) % add_rows, :] BEFORE the norm -- VisionAdapter's
- * `t + view_embed[v]`, vision_adapter.py:122).  Writes y_f32 and/or y_bf16 (either may be NULL). */
+ * `t + view_embed[v]`, vision_adapter.py:122) and an optional table added AFTER the norm,
+ * y[r,:] += post_add[r % post_rows, :] (VATLiDAR's cached geo_pe + view_embed[sid], vat_lidar.py:235-248).
+ * Writes y_f32 and/or y_bf16 (+ y_lo). */
 int lvq_layernorm(const float *x, const float *add, int add_rows, int add_group, const float *gamma,
-                  const float *beta, float eps, int64_t rows, int d, float *y_f32, lvq_bf16 *y_bf16,
-                  lvq_stream_t stream);
+                  const float *beta, float eps, int64_t rows, int d, const float *post_add, int64_t post_rows,
+                  float *y_f32, lvq_bf16 *y_bf16, lvq_bf16 *y_lo, lvq_stream_t stream);
 
 /* Linear layer on MFMA bf16 tiles with fp32 accumulation (nn.Linear / 1x1 Conv2d / MHA in_proj,
  * out_proj; vat_blocks.py:28-34, vat_lidar.py:88,93-97,117-120, vat_vision.py:118-137,
- * build_linear.py:18-19):
- *   C[m, n] = epi( sum_k A[m,k] * W[n,k] + bias[n] )                    A [M,K] bf16, W [N,K] bf16
- *   epi: flags & LVQ_GEMM_GELU -> exact erf GELU;  then * alpha;
- *        + residual[m,n] (fp32 [M,N]) if residual != NULL;
- *        + rowtab[(m % rowtab_rows), n] (fp32) if rowtab != NULL (input-independent positional tables:
- *          geo_pe + view_embed[sid] of vat_lidar.py:235-248)
- *   outputs: c_f32 [M,N] and/or c_bf16 [M,N] (either may be NULL).
- *   precision: 1 = plain bf16 operands; 3 = split-bf16 (A and W each given as hi + lo parts:
- *   a_lo / w_lo non-NULL; computes hi*hi + hi*lo + lo*hi, ~fp32-accurate products on bf16 MFMA). */
+ * build_linear.py:18-19), batched over `batch` problems with element strides a_bs / w_bs / c_bs:
+ *   C[z][m, n] = epi( sum_k A[z][m,k] * W[z][n,k] )     A rows lda apart, W rows ldw apart, C rows ldc apart
+ *   epi(x): x += bias[n]; GELU(x) (exact erf) if flags & LVQ_GEMM_GELU; x *= alpha;
+ *           x += residual[z][m,n] (fp32, same layout as C) ; x += rowtab[(m % rowtab_rows), n] (fp32 [rows,N]:
+ *           input-independent positional tables, geo_pe + view_embed[sid] of vat_lidar.py:235-248)
+ *   outputs: c_f32 and/or c_bf16 (+ c_lo).  a_lo / w_lo both NULL (bf16) or both non-NULL (bf16x3).
+ *   Requirements: k, lda, ldw, a_bs, w_bs multiples of 8; 16-byte aligned operand bases (else LVQ_EUNSUPPORTED). */
 enum { LVQ_GEMM_GELU = 1 };
 int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo,
                   const float *bias, const float *residual, const float *rowtab, int64_t rowtab_rows,
-                  float alpha, int flags, int64_t m, int n, int k, float *c_f32, lvq_bf16 *c_bf16,
-                  lvq_stream_t stream);
+                  float alpha, int flags, int64_t m, int n, int k, int64_t lda, int64_t ldw, int64_t ldc,
+                  int batch, int64_t a_bs, int64_t w_bs, int64_t c_bs, float *c_f32, lvq_bf16 *c_bf16,
+                  lvq_bf16 *c_lo, lvq_stream_t stream);
 
-/* fp32 -> bf16 (round-to-nearest-even) with optional lo part (x - bf16(x)) for the split mode. */
+/* fp32 -> bf16 (round-to-nearest-even) with optional lo part (x - bf16(x)) for the bf16x3 mode. */
 int lvq_cast_bf16(const float *x, int64_t n, lvq_bf16 *hi, lvq_bf16 *lo, lvq_stream_t stream);
+/* out = (hi + lo) * alpha as fp32 (lo may be NULL): hands attention outputs back to fp32 callers. */
+int lvq_bf16_to_f32(const lvq_bf16 *hi, const lvq_bf16 *lo, int64_t n, float alpha, float *out, lvq_stream_t stream);
 
 /* Attention core = F.scaled_dot_product_attention inside nn.MultiheadAttention (vat_blocks.py:39,42)
  * and deepencoder sdp_attention (clip_sdpa.py:50-66, sam_vary_sdpa.py:27-42):
  *   O[b,i,h,:] = softmax_j( Q[b,i,h,:].K[b,j,h,:] * scale + bias[b,h,i,j] ) V[b,j,h,:]
- *   q [B,Nq,*] rows of stride ldq elements, head h at column offset h*dh (same for k, v, o), so packed
- *   [B,N,3d] in_proj outputs and [B,H,S,D] tensors are both addressable without a copy:
- *   q element (b,i,h,e) at q[(b*q_bstride) + i*ldq + h*q_hstride + e].
- *   bias (optional, fp32 [B,H,Nq,Nkv]) ; causal != 0 adds the lower-triangular mask aligned to the END
+ *   element (b,i,h,e) of q lives at q[b*q_bstride + i*ldq + h*q_hstride + e] (same for k, v, o), so packed
+ *   [B,N,3d] in_proj outputs and [B,H,S,D] tensors are both addressable without a copy.
+ *   bias (optional, fp32 [B,H,Nq,Nkv]); causal != 0 adds the lower-triangular mask aligned to the END
  *   (query i sees keys j <= i + Nkv - Nq), used by the stand-in decoder head.
  *   n_kv_heads < n_heads => grouped-query attention (head h reads kv head h / (n_heads/n_kv_heads)).
- *   Online softmax, statistics and accumulation in fp32; dh any multiple of 16 up to 1024. */
-int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *k, const lvq_bf16 *v, const float *bias,
-                       int batch, int n_heads, int n_kv_heads, int nq, int nkv, int dh,
-                       int64_t q_bstride, int64_t ldq, int64_t q_hstride,
-                       int64_t k_bstride, int64_t ldk, int64_t k_hstride,
-                       int64_t v_bstride, int64_t ldv, int64_t v_hstride,
-                       int64_t o_bstride, int64_t ldo, int64_t o_hstride,
-                       float scale, int causal, lvq_bf16 *o, lvq_stream_t stream);
+ *   Online softmax, statistics and accumulation in fp32.  dh multiple of 16 and <= 128: fused flash
+ *   kernel, no workspace.  Larger dh (448, 1024: the reference's 2-head defaults) or dh % 16 == 8: split
+ *   path (scores GEMM -> row softmax -> PV GEMM) using the workspace; needs n_heads == n_kv_heads. */
+size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, int nkv, int dh, int precision);
+int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k, const lvq_bf16 *k_lo,
+                       const lvq_bf16 *v, const lvq_bf16 *v_lo, const float *bias, int batch, int n_heads,
+                       int n_kv_heads, int nq, int nkv, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride,
+                       int64_t k_bstride, int64_t ldk, int64_t k_hstride, int64_t v_bstride, int64_t ldv,
+                       int64_t v_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, int causal,
+                       lvq_bf16 *o, lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream);
 
 /* VATLiDAR front (vat_lidar.py:82-85,212): depthwise Conv2d(C,C,3,pad=1,groups=C) + exact GELU on
  * NCHW fp32 input, written TOKEN-MAJOR [B, H*W, C] as bf16 (the A operand of the 1x1-conv GEMM). */
@@ -196,19 +205,21 @@ int lvq_dwconv3x3_gelu(const float *bev, const float *w9, const float *bias, int
                        lvq_bf16 *tokens_hi, lvq_bf16 *tokens_lo, lvq_stream_t stream);
 
 /* out[r, :] = x[r, :] * alpha + add[(r % add_rows), :]  (query = query + view_embed chunk,
- * vat_lidar.py:259-270; prefix * prefix_scale, trainer.py:581,594) -- fp32 elementwise. */
+ * vat_lidar.py:259-270; prefix * prefix_scale, trainer.py:581,594) -- fp32 elementwise; add may be NULL. */
 int lvq_scale_add_rows(const float *x, const float *add, int64_t add_rows, float alpha, int64_t rows, int d,
                        float *out, lvq_stream_t stream);
 
 /* Stand-in decoder head pieces (Qwen2-style; validation.py:146-156 drives `base(inputs_embeds, labels)`):
- * RMSNorm, rotary embedding applied in place to packed q|k projections, SiLU(gate)*up. */
+ * RMSNorm, rotary embedding applied in place to a packed projection (rows = B*L, position = row % seq_len),
+ * SiLU(gate)*up on a packed [rows, 2*inter] gate|up projection, and the shifted-label cross entropy. */
 int lvq_rmsnorm(const float *x, const float *gamma, float eps, int64_t rows, int d, float *y_f32, lvq_bf16 *y_bf16,
                 lvq_bf16 *y_lo, lvq_stream_t stream);
-int lvq_rope_inplace(lvq_bf16 *x, int64_t rows, int seq_len, int n_heads, int dh, int64_t ld, float theta,
+int lvq_rope_inplace(lvq_bf16 *x, lvq_bf16 *x_lo, int64_t rows, int seq_len, int n_heads, int dh, int64_t ld, float theta,
                      lvq_stream_t stream);
 int lvq_swiglu(const float *gate_up, int64_t rows, int inter, lvq_bf16 *out_hi, lvq_bf16 *out_lo, lvq_stream_t stream);
-/* mean shifted cross-entropy over labels != -100 (transformers causal-LM loss): logits [rows,vocab] fp32,
- * labels [rows] int64 already shifted by the caller; loss_sum_cnt [2] fp32 accumulators (zero on entry). */
+/* sum over rows with labels[row] >= 0 of (logsumexp(logits[row]) - logits[row, label]) and their count:
+ * loss = loss_sum_cnt[0] / loss_sum_cnt[1] (transformers causal-LM loss; labels already shifted by the
+ * caller, -100 = ignore).  loss_sum_cnt [2] fp32 must be zero on entry. */
 int lvq_cross_entropy(const float *logits, const int64_t *labels, int64_t rows, int vocab, float *loss_sum_cnt,
                       lvq_stream_t stream);
 

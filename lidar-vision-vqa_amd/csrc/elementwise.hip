@@ -1,0 +1,255 @@
+// csrc/elementwise.hip -- the memory-bound glue around the MFMA kernels (fp32 statistics, bf16 hand-off).
+//
+//   lvq_layernorm       nn.LayerNorm (vat_blocks.py:19,23,27; vat_lidar.py:89,114,116; vision_adapter.py:56,122-125)
+//   lvq_dwconv3x3_gelu  VATLiDAR.refine (vat_lidar.py:82-85): depthwise 3x3 + exact GELU, NCHW -> token-major bf16
+//   lvq_scale_add_rows  query + view_embed / prefix * prefix_scale (vat_lidar.py:259-270; trainer.py:581,594)
+//   lvq_rmsnorm / lvq_rope_inplace / lvq_swiglu / lvq_cross_entropy   stand-in decoder head (validation.py:146-156)
+//
+// Every kernel writes the bf16 operand (and, for the bf16x3 mode, its lo residual) that the NEXT MFMA
+// kernel consumes, so normalised activations never make an fp32 round trip through HBM.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__device__ __forceinline__ void put_out(float y, int64_t o, float *y32, uint16_t *y16, uint16_t *ylo) {
+    if (y32) y32[o] = y;
+    if (y16) {
+        const uint16_t h = f32_to_bf16(y);
+        y16[o] = h;
+        if (ylo) ylo[o] = f32_to_bf16(y - bf16_to_f32(h));
+    }
+}
+
+// one wave per row, three passes over a row that stays in L1/L2 (d <= 2048 floats = 8 KB)
+template <bool RMS>
+__global__ void __launch_bounds__(256) k_norm(const float *__restrict__ x, const float *__restrict__ add, int add_rows,
+                                              int add_group, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                              float eps, int64_t rows, int d, const float *__restrict__ post,
+                                              int64_t post_rows, float *__restrict__ y32,
+                                              uint16_t *__restrict__ y16, uint16_t *__restrict__ ylo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * d;
+    const float *ar = add ? add + ((row / add_group) % add_rows) * (int64_t)d : nullptr;
+    float mean = 0.f;
+    if (!RMS) {
+        float s = 0.f;
+        for (int k = lane; k < d; k += 64) s += xr[k] + (ar ? ar[k] : 0.f);
+        mean = wave_sum(s) / (float)d;
+    }
+    float v = 0.f;
+    for (int k = lane; k < d; k += 64) {
+        const float t = xr[k] + (ar ? ar[k] : 0.f) - mean;
+        v += t * t;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
+    const float *pr = post ? post + (row % post_rows) * (int64_t)d : nullptr;
+    for (int k = lane; k < d; k += 64) {
+        const float t = (xr[k] + (ar ? ar[k] : 0.f) - mean) * rstd;
+        float y = RMS ? gamma[k] * t : t * gamma[k] + (beta ? beta[k] : 0.f);
+        if (pr) y += pr[k];
+        put_out(y, row * d + k, y32, y16, ylo);
+    }
+}
+
+// depthwise 3x3 (pad 1) + GELU: block = 32 channels x one image row segment of 64 pixels
+__global__ void __launch_bounds__(256) k_dwconv3x3_gelu(const float *__restrict__ bev, const float *__restrict__ w9,
+                                                        const float *__restrict__ bias, int C, int H, int W,
+                                                        uint16_t *__restrict__ thi, uint16_t *__restrict__ tlo) {
+    __shared__ float tile[32][3][68];       // [channel][row y-1..y+1][x0-1 .. x0+64] (+pad)
+    __shared__ float outv[64][33];          // [pixel][channel] (+1 pad)
+    const int x0 = blockIdx.x * 64, y = blockIdx.y;
+    const int cblocks = (C + 31) / 32;
+    const int b = blockIdx.z / cblocks, c0 = (blockIdx.z % cblocks) * 32;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 32 * 3 * 66; e += 256) {
+        const int xx = e % 66, r = (e / 66) % 3, c = e / (66 * 3);
+        const int gx = x0 + xx - 1, gy = y + r - 1, gc = c0 + c;
+        float v = 0.f;
+        if (gc < C && gx >= 0 && gx < W && gy >= 0 && gy < H) v = bev[(((int64_t)b * C + gc) * H + gy) * W + gx];
+        tile[c][r][xx] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < 32 * 64; e += 256) {
+        const int xx = e & 63, c = e >> 6, gc = c0 + c;
+        float acc = 0.f;
+        if (gc < C) {
+            const float *wk = w9 + gc * 9;
+            acc = bias ? bias[gc] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s = 0; s < 3; ++s) acc = fmaf(tile[c][r][xx + s], wk[r * 3 + s], acc);
+            acc = gelu_erf(acc);
+        }
+        outv[xx][c] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * 32; e += 256) {
+        const int c = e & 31, xx = e >> 5, gx = x0 + xx, gc = c0 + c;
+        if (gx < W && gc < C) {
+            const int64_t o = ((int64_t)b * H * W + (int64_t)y * W + gx) * C + gc;
+            const float v = outv[xx][c];
+            const uint16_t h = f32_to_bf16(v);
+            thi[o] = h;
+            if (tlo) tlo[o] = f32_to_bf16(v - bf16_to_f32(h));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_scale_add_rows(const float *__restrict__ x, const float *__restrict__ add,
+                                                        int64_t add_rows, float alpha, int64_t rows, int d,
+                                                        float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * d) return;
+    const int64_t r = i / d;
+    const int k = (int)(i - r * d);
+    float v = x[i] * alpha;
+    if (add) v += add[(r % add_rows) * d + k];
+    out[i] = v;
+}
+
+// rotate-half rotary embedding (transformers Qwen2): x[..., :h] , x[..., h:] with angle pos * theta^(-2i/dh)
+__global__ void __launch_bounds__(256) k_rope(uint16_t *__restrict__ xh, uint16_t *__restrict__ xl, int64_t rows, int seq_len,
+                                              int n_heads, int dh, int64_t ld, float theta) {
+    const int half = dh >> 1;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * n_heads * half) return;
+    const int e = (int)(i % half);
+    const int hd = (int)((i / half) % n_heads);
+    const int64_t row = i / ((int64_t)half * n_heads);
+    const int pos = (int)(row % seq_len);
+    const float inv = powf(theta, -2.0f * (float)e / (float)dh);
+    float sn, cs;
+    sincosf((float)pos * inv, &sn, &cs);
+    const int64_t o1 = row * ld + (int64_t)hd * dh + e, o2 = o1 + half;
+    const float a = bf16_to_f32(xh[o1]) + (xl ? bf16_to_f32(xl[o1]) : 0.f);
+    const float b = bf16_to_f32(xh[o2]) + (xl ? bf16_to_f32(xl[o2]) : 0.f);
+    const float ra = a * cs - b * sn, rb = b * cs + a * sn;
+    const uint16_t ha = f32_to_bf16(ra), hb = f32_to_bf16(rb);
+    xh[o1] = ha; xh[o2] = hb;
+    if (xl) { xl[o1] = f32_to_bf16(ra - bf16_to_f32(ha)); xl[o2] = f32_to_bf16(rb - bf16_to_f32(hb)); }
+}
+
+__global__ void __launch_bounds__(256) k_swiglu(const float *__restrict__ gu, int64_t rows, int inter, uint16_t *__restrict__ oh,
+                                                uint16_t *__restrict__ ol) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * inter) return;
+    const int64_t r = i / inter;
+    const int k = (int)(i - r * inter);
+    const float g = gu[r * 2 * inter + k], u = gu[r * 2 * inter + inter + k];
+    const float v = g / (1.0f + expf(-g)) * u;
+    const uint16_t h = f32_to_bf16(v);
+    oh[i] = h;
+    if (ol) ol[i] = f32_to_bf16(v - bf16_to_f32(h));
+}
+
+// one wave per row: loss_sum += logsumexp(row) - row[label]; cnt += 1 (labels == -100 are skipped)
+__global__ void __launch_bounds__(256) k_cross_entropy(const float *__restrict__ logits, const int64_t *__restrict__ labels,
+                                                       int64_t rows, int vocab, float *__restrict__ acc2) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t lab = labels[row];
+    if (lab < 0 || lab >= vocab) return;
+    const float *lr = logits + row * vocab;
+    float mx = -INFINITY;
+    for (int k = lane; k < vocab; k += 64) mx = fmaxf(mx, lr[k]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int k = lane; k < vocab; k += 64) s += expf(lr[k] - mx);
+    s = wave_sum(s);
+    if (lane == 0) {
+        atomicAdd(&acc2[0], logf(s) + mx - lr[lab]);
+        atomicAdd(&acc2[1], 1.0f);
+    }
+}
+
+}  // namespace
+
+extern "C" int lvq_layernorm(const float *x, const float *add, int add_rows, int add_group, const float *gamma,
+                             const float *beta, float eps, int64_t rows, int d, const float *post_add, int64_t post_rows,
+                             float *y_f32, lvq_bf16 *y_bf16, lvq_bf16 *y_lo, lvq_stream_t stream) {
+    if (rows < 0 || d <= 0 || !gamma || (!y_f32 && !y_bf16) || (y_lo && !y_bf16)) return LVQ_EINVAL;
+    if (add && (add_rows <= 0 || add_group <= 0)) return LVQ_EINVAL;
+    if (post_add && post_rows <= 0) return LVQ_EINVAL;
+    if (rows == 0) return LVQ_OK;
+    if (!x) return LVQ_EINVAL;
+    hipLaunchKernelGGL(k_norm<false>, dim3((unsigned)lvq_cdiv(rows, 4)), dim3(256), 0, lvq_s(stream), x, add, add_rows,
+                       add_group < 1 ? 1 : add_group, gamma, beta, eps, rows, d, post_add, post_rows < 1 ? 1 : post_rows, y_f32,
+                       y_bf16, y_lo);
+    return lvq_launch_status();
+}
+
+extern "C" int lvq_rmsnorm(const float *x, const float *gamma, float eps, int64_t rows, int d, float *y_f32, lvq_bf16 *y_bf16,
+                           lvq_bf16 *y_lo, lvq_stream_t stream) {
+    if (rows < 0 || d <= 0 || !gamma || (!y_f32 && !y_bf16) || (y_lo && !y_bf16)) return LVQ_EINVAL;
+    if (rows == 0) return LVQ_OK;
+    if (!x) return LVQ_EINVAL;
+    hipLaunchKernelGGL(k_norm<true>, dim3((unsigned)lvq_cdiv(rows, 4)), dim3(256), 0, lvq_s(stream), x, (const float *)nullptr,
+                       1, 1, gamma, (const float *)nullptr, eps, rows, d, (const float *)nullptr, (int64_t)1, y_f32, y_bf16, y_lo);
+    return lvq_launch_status();
+}
+
+extern "C" int lvq_dwconv3x3_gelu(const float *bev, const float *w9, const float *bias, int batch, int ch, int h, int w,
+                                  lvq_bf16 *tokens_hi, lvq_bf16 *tokens_lo, lvq_stream_t stream) {
+    if (batch <= 0 || ch <= 0 || h <= 0 || w <= 0 || !bev || !w9 || !tokens_hi) return LVQ_EINVAL;
+    const int cblocks = (ch + 31) / 32;
+    if ((int64_t)batch * cblocks > 65535 || h > 65535) return LVQ_EUNSUPPORTED;
+    dim3 grid((unsigned)lvq_cdiv(w, 64), (unsigned)h, (unsigned)(batch * cblocks));
+    hipLaunchKernelGGL(k_dwconv3x3_gelu, grid, dim3(256), 0, lvq_s(stream), bev, w9, bias, ch, h, w, tokens_hi, tokens_lo);
+    return lvq_launch_status();
+}
+
+extern "C" int lvq_scale_add_rows(const float *x, const float *add, int64_t add_rows, float alpha, int64_t rows, int d,
+                                  float *out, lvq_stream_t stream) {
+    if (rows < 0 || d <= 0 || (add && add_rows <= 0)) return LVQ_EINVAL;
+    if (rows == 0) return LVQ_OK;
+    if (!x || !out) return LVQ_EINVAL;
+    hipLaunchKernelGGL(k_scale_add_rows, dim3((unsigned)lvq_cdiv(rows * d, 256)), dim3(256), 0, lvq_s(stream), x, add,
+                       add_rows < 1 ? 1 : add_rows, alpha, rows, d, out);
+    return lvq_launch_status();
+}
+
+extern "C" int lvq_rope_inplace(lvq_bf16 *x, lvq_bf16 *x_lo, int64_t rows, int seq_len, int n_heads, int dh, int64_t ld,
+                                float theta, lvq_stream_t stream) {
+    if (rows < 0 || seq_len <= 0 || n_heads <= 0 || dh <= 0 || (dh & 1) || ld < (int64_t)n_heads * dh) return LVQ_EINVAL;
+    if (rows == 0) return LVQ_OK;
+    if (!x) return LVQ_EINVAL;
+    const int64_t n = rows * n_heads * (dh / 2);
+    hipLaunchKernelGGL(k_rope, dim3((unsigned)lvq_cdiv(n, 256)), dim3(256), 0, lvq_s(stream), x, x_lo, rows, seq_len, n_heads,
+                       dh, ld, theta);
+    return lvq_launch_status();
+}
+
+extern "C" int lvq_swiglu(const float *gate_up, int64_t rows, int inter, lvq_bf16 *out_hi, lvq_bf16 *out_lo,
+                          lvq_stream_t stream) {
+    if (rows < 0 || inter <= 0) return LVQ_EINVAL;
+    if (rows == 0) return LVQ_OK;
+    if (!gate_up || !out_hi) return LVQ_EINVAL;
+    hipLaunchKernelGGL(k_swiglu, dim3((unsigned)lvq_cdiv(rows * inter, 256)), dim3(256), 0, lvq_s(stream), gate_up, rows,
+                       inter, out_hi, out_lo);
+    return lvq_launch_status();
+}
+
+extern "C" int lvq_cross_entropy(const float *logits, const int64_t *labels, int64_t rows, int vocab, float *loss_sum_cnt,
+                                 lvq_stream_t stream) {
+    if (rows < 0 || vocab <= 0 || !loss_sum_cnt) return LVQ_EINVAL;
+    if (rows == 0) return LVQ_OK;
+    if (!logits || !labels) return LVQ_EINVAL;
+    hipLaunchKernelGGL(k_cross_entropy, dim3((unsigned)lvq_cdiv(rows, 4)), dim3(256), 0, lvq_s(stream), logits, labels, rows,
+                       vocab, loss_sum_cnt);
+    return lvq_launch_status();
+}

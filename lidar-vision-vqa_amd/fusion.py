@@ -1,0 +1,396 @@
+"""Fusion side of the hot path with the reference's nn.Module API, MI355X-native.
+
+Drop-in for (citations relative to /root/reference/src/):
+  VATBlock        encoder-decoder/training/models/vat_blocks.py:7-47
+  VATLiDAR        encoder-decoder/training/models/vat_lidar.py:42-304
+  VATVision       encoder-decoder/training/models/vat_vision.py:20-235
+  VisionAdapter   encoder-decoder/training/models/vision_adapter.py:35-145
+  sdp_attention   deepencoder/clip_sdpa.py:50-66 (== sam_vary_sdpa.py:27-42)
+  deepencoder_fuse  deepencoder/deepencoder_infer.py:505-511 + build_linear.py:18-19
+
+Same constructor signatures, same `state_dict()` keys and shapes (SURVEY.md Appendix D -- torch's
+nn.LayerNorm / nn.Linear / nn.MultiheadAttention / nn.Conv2d objects are kept as PARAMETER CONTAINERS so
+checkpoints load unchanged and default initialisation consumes the RNG exactly like the reference),
+same forward signatures, fp32 in / fp32 out.  The forward pass never calls those containers: all
+arithmetic runs in liblvq_hip.so (bf16 MFMA, fp32 statistics/accumulation).
+
+Inference only: forward under torch.is_grad_enabled() with trainable inputs/params raises (the
+reference's autograd/training path is not part of this round's scope); dropout is the identity,
+as in the reference's eval() mode.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _ffi as F
+from . import ops
+from .ops import BF
+
+NUM_VIEWS = 6  # vat_lidar.py:39
+CAM_VIEWS = ("CAM_FRONT", "CAM_FRONT_RIGHT", "CAM_FRONT_LEFT", "CAM_BACK", "CAM_BACK_RIGHT", "CAM_BACK_LEFT")
+
+
+class _HipModule(nn.Module):
+    """Shared plumbing: precision switch, bf16 weight cache keyed on the parameter version."""
+
+    def __init__(self):
+        super().__init__()
+        object.__setattr__(self, "_wcache", {})
+        self.precision: Optional[str] = None   # None -> ops.default_precision()
+
+    def _split(self) -> bool:
+        return (self.precision or ops.default_precision()) == "bf16x3"
+
+    def _w(self, p: torch.Tensor, pad_k: int = 0) -> BF:
+        """bf16 (hi[, lo]) copy of a weight matrix [N,K]; rebuilt when the parameter changes."""
+        split = self._split()
+        key = (id(p), split)
+        ver = (p.data_ptr(), p._version, tuple(p.shape), p.device)
+        hit = self._wcache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        w = p.detach().reshape(p.shape[0], -1).float()
+        if pad_k and w.shape[1] % pad_k:
+            w = torch.nn.functional.pad(w, (0, pad_k - w.shape[1] % pad_k))
+        bf = ops.cast(w.contiguous(), split)
+        self._wcache[key] = (ver, bf)
+        return bf
+
+    def _guard(self, *tensors):
+        if self.training:
+            raise F.LvqError(f"{type(self).__name__}: the MI355X path is inference-only; call .eval() "
+                             "(dropout is the identity there, as in the reference)")
+        if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors if t is not None)
+                                        or any(p.requires_grad for p in self.parameters())):
+            raise F.LvqError(f"{type(self).__name__}: autograd is not implemented on the HIP path; wrap the call in torch.no_grad()")
+        F.require_cuda(*[t for t in tensors if t is not None])
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    return (t if t.dtype == torch.float32 else t.float()).contiguous()
+
+
+class VATBlock(_HipModule):
+    """q [B,nq,d], kv [B,N_kv,d] -> [B,nq,d]: pre-LN self-attn, pre-LN cross-attn(q -> kv), pre-LN MLP."""
+
+    def __init__(self, d_model: int, n_heads: int, d_mlp: int, dropout: float):
+        super().__init__()
+        self.sa_ln = nn.LayerNorm(d_model)
+        self.sa = nn.MultiheadAttention(d_model, n_heads, dropout=dropout, batch_first=True)
+        self.ca_ln = nn.LayerNorm(d_model)
+        self.ca = nn.MultiheadAttention(d_model, n_heads, dropout=dropout, batch_first=True)
+        self.mlp_ln = nn.LayerNorm(d_model)
+        self.mlp = nn.Sequential(nn.Linear(d_model, d_mlp), nn.GELU(), nn.Dropout(dropout), nn.Linear(d_mlp, d_model),
+                                 nn.Dropout(dropout))
+        self.d_model, self.n_heads = d_model, n_heads
+        if d_model % n_heads or (d_model // n_heads) % 8:
+            raise ValueError("head_dim must be a multiple of 8 for the MFMA attention kernels")
+
+    # ---- pieces (2-D token-major tensors) -------------------------------------------------------
+    def _self_attn(self, q2: torch.Tensor, B: int, nq: int) -> torch.Tensor:
+        d, h = self.d_model, self.n_heads
+        dh = d // h
+        split = self._split()
+        _, qn = ops.layernorm(q2, self.sa_ln.weight, self.sa_ln.bias, self.sa_ln.eps, split)
+        _, qkv = ops.linear(qn, self._w(self.sa.in_proj_weight), self.sa.in_proj_bias, out_bf=True)
+        sl = lambda t, c: (t[0][:, c * d:], None if t[1] is None else t[1][:, c * d:])
+        st = (nq * 3 * d, 3 * d, dh)
+        o = ops.attention(sl(qkv, 0), sl(qkv, 1), sl(qkv, 2), batch=B, n_heads=h, n_kv_heads=h, nq=nq, nkv=nq, dh=dh,
+                          q_strides=st, k_strides=st, v_strides=st, scale=1.0 / math.sqrt(dh))
+        y, _ = ops.linear(o, self._w(self.sa.out_proj.weight), self.sa.out_proj.bias, residual=q2, out_f32=True)
+        return y
+
+    def project_kv(self, kv_bf: BF) -> BF:
+        """K|V projection of the cross-attention: [B*Nkv, d] -> [B*Nkv, 2d] (rows d..3d of in_proj)."""
+        d = self.d_model
+        _, kvp = ops.linear(kv_bf, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(d, 3 * d))
+        return kvp
+
+    def _cross_attn(self, q2: torch.Tensor, kvp: BF, B: int, nq: int, nkv: int) -> torch.Tensor:
+        d, h = self.d_model, self.n_heads
+        dh = d // h
+        split = self._split()
+        _, qn = ops.layernorm(q2, self.ca_ln.weight, self.ca_ln.bias, self.ca_ln.eps, split)
+        _, qp = ops.linear(qn, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(0, d))
+        vsl = (kvp[0][:, d:], None if kvp[1] is None else kvp[1][:, d:])
+        o = ops.attention(qp, kvp, vsl, batch=B, n_heads=h, n_kv_heads=h, nq=nq, nkv=nkv, dh=dh,
+                          q_strides=(nq * d, d, dh), k_strides=(nkv * 2 * d, 2 * d, dh), v_strides=(nkv * 2 * d, 2 * d, dh),
+                          scale=1.0 / math.sqrt(dh))
+        y, _ = ops.linear(o, self._w(self.ca.out_proj.weight), self.ca.out_proj.bias, residual=q2, out_f32=True)
+        return y
+
+    def _mlp(self, q2: torch.Tensor) -> torch.Tensor:
+        split = self._split()
+        _, hn = ops.layernorm(q2, self.mlp_ln.weight, self.mlp_ln.bias, self.mlp_ln.eps, split)
+        _, h1 = ops.linear(hn, self._w(self.mlp[0].weight), self.mlp[0].bias, gelu=True, out_bf=True)
+        y, _ = ops.linear(h1, self._w(self.mlp[3].weight), self.mlp[3].bias, residual=q2, out_f32=True)
+        return y
+
+    def forward_tokens(self, q2: torch.Tensor, kv_bf: BF, B: int, nq: int, nkv: int) -> torch.Tensor:
+        q2 = self._self_attn(q2, B, nq)
+        q2 = self._cross_attn(q2, self.project_kv(kv_bf), B, nq, nkv)
+        return self._mlp(q2)
+
+    def forward(self, q: torch.Tensor, kv: torch.Tensor) -> torch.Tensor:
+        self._guard(q, kv)
+        B, nq, d = q.shape
+        nkv = kv.shape[1]
+        assert d == self.d_model and kv.shape[0] == B and kv.shape[2] == d
+        kv_bf = ops.cast(_f32(kv).view(B * nkv, d), self._split())
+        out = self.forward_tokens(_f32(q).view(B * nq, d), kv_bf, B, nq, nkv)
+        return out.view(B, nq, d)
+
+    def cross_attention(self, q: torch.Tensor, kv: torch.Tensor) -> torch.Tensor:
+        """Only the `q + ca(ca_ln(q), kv, kv)` sub-path (vat_blocks.py:42): the headline kernel sequence."""
+        self._guard(q, kv)
+        B, nq, d = q.shape
+        nkv = kv.shape[1]
+        kv_bf = ops.cast(_f32(kv).view(B * nkv, d), self._split())
+        return self._cross_attn(_f32(q).view(B * nq, d), self.project_kv(kv_bf), B, nq, nkv).view(B, nq, d)
+
+
+def _lidar_grid_cpu(H: int, W: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """geom [HW,5] = (x, y, r, sin t, cos t), sid [HW] -- input-independent, cached per (H, W, device).
+    Evaluated with the reference's exact torch expressions on the host (vat_lidar.py:143-182) so the sector
+    ids are bit-identical to the CPU reference, then uploaded once."""
+    yv, xv = torch.meshgrid(torch.linspace(-1.0, 1.0, H), torch.linspace(-1.0, 1.0, W), indexing="ij")
+    r = torch.clamp((xv ** 2 + yv ** 2).sqrt(), 0.0, 1.0)
+    theta = torch.atan2(yv, xv)
+    geom = torch.stack((xv, yv, r, torch.sin(theta), torch.cos(theta)), dim=-1).view(H * W, 5)
+    ft = theta.view(-1)
+    pi = math.pi
+    sid = torch.empty(H * W, dtype=torch.long)
+    sid[(ft >= pi / 3) & (ft < 2 * pi / 3)] = 0
+    sid[(ft >= 0.0) & (ft < pi / 3)] = 1
+    sid[(ft >= 2 * pi / 3) & (ft <= pi)] = 2
+    sid[(ft >= -2 * pi / 3) & (ft < -pi / 3)] = 3
+    sid[(ft >= -pi / 3) & (ft < 0.0)] = 4
+    sid[(ft >= -pi) & (ft < -2 * pi / 3)] = 5
+    return geom, sid
+
+
+def _post_head(mod: _HipModule, q2: torch.Tensor, final_ln: nn.LayerNorm, post: nn.Sequential) -> torch.Tensor:
+    """final_ln -> LayerNorm -> Linear -> GELU -> (Dropout) -> Linear (vat_lidar.py:295-296, vat_vision.py:214-215)."""
+    split = mod._split()
+    qf, _ = ops.layernorm(q2, final_ln.weight, final_ln.bias, final_ln.eps, split, want_f32=True, want_bf=False)
+    _, hn = ops.layernorm(qf, post[0].weight, post[0].bias, post[0].eps, split)
+    _, h1 = ops.linear(hn, mod._w(post[1].weight), post[1].bias, gelu=True, out_bf=True)
+    y, _ = ops.linear(h1, mod._w(post[4].weight), post[4].bias, out_f32=True)
+    return y
+
+
+class VATLiDAR(_HipModule):
+    """bev [B,C_in,H,W] -> view-aware tokens [B,n_queries,d_model]."""
+
+    def __init__(self, c_in: int, d_model: int, n_queries: int = 576, n_layers: int = 4, n_heads: int = 8,
+                 mlp_ratio: float = 4.0, dropout: float = 0.10, post_dropout: float = 0.10):
+        super().__init__()
+        assert n_queries % NUM_VIEWS == 0, "n_queries must be divisible by NUM_VIEWS (6)."
+        self.d_model = d_model
+        self.n_queries = n_queries
+        self.nq_per_view = n_queries // NUM_VIEWS
+        self.refine = nn.Sequential(nn.Conv2d(c_in, c_in, kernel_size=3, padding=1, groups=c_in), nn.GELU())
+        self.proj = nn.Conv2d(c_in, d_model, kernel_size=1, bias=True)
+        self.norm_tokens = nn.LayerNorm(d_model)
+        self.geo_mlp = nn.Sequential(nn.Linear(5, d_model), nn.GELU(), nn.Linear(d_model, d_model))
+        self.view_embed = nn.Parameter(torch.zeros(NUM_VIEWS, d_model))
+        self.query = nn.Parameter(torch.randn(n_queries, d_model) * 0.02)
+        d_ff = int(mlp_ratio * d_model)
+        self.blocks = nn.ModuleList([VATBlock(d_model, n_heads, d_ff, dropout) for _ in range(n_layers)])
+        self.final_ln = nn.LayerNorm(d_model)
+        self.post = nn.Sequential(nn.LayerNorm(d_model), nn.Linear(d_model, d_model), nn.GELU(), nn.Dropout(post_dropout),
+                                  nn.Linear(d_model, d_model))
+        self._cache: Dict[Tuple[int, int, torch.device], Tuple[torch.Tensor, torch.Tensor]] = {}
+        object.__setattr__(self, "_pe_cache", {})
+        if c_in % 8:
+            raise ValueError("c_in must be a multiple of 8 (16-byte bf16 operand loads)")
+
+    def _grid(self, H: int, W: int, device: torch.device):
+        key = (H, W, device)
+        if key not in self._cache:
+            geom, sid = _lidar_grid_cpu(H, W)
+            self._cache[key] = (geom.to(device), sid.to(device))
+        return self._cache[key]
+
+    def _pe_table(self, H: int, W: int, device) -> torch.Tensor:
+        """geo_mlp(geom) + view_embed[sid]: [HW, d] fp32, input-independent -> cached per weights version."""
+        split = self._split()
+        params = (self.geo_mlp[0].weight, self.geo_mlp[0].bias, self.geo_mlp[2].weight, self.geo_mlp[2].bias, self.view_embed)
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (split,)
+        key = (H, W, device)
+        hit = self._pe_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        geom, sid = self._grid(H, W, device)
+        g8 = torch.nn.functional.pad(geom, (0, 3)).contiguous()            # K = 5 -> 8 (zero columns)
+        _, h1 = ops.linear(ops.cast(g8, split), self._w(self.geo_mlp[0].weight, pad_k=8), self.geo_mlp[0].bias, gelu=True,
+                           out_bf=True)
+        ve = self.view_embed.detach().float()[sid].contiguous()            # gather of a 6-row table (index plumbing)
+        pe, _ = ops.linear(h1, self._w(self.geo_mlp[2].weight), self.geo_mlp[2].bias, residual=ve, out_f32=True)
+        self._pe_cache[key] = (ver, pe)
+        return pe
+
+    def bev_tokens(self, bev: torch.Tensor) -> BF:
+        """vat_lidar.py:212-248: refine -> proj -> LayerNorm -> + geo PE + view embed; BF [B*HW, d]."""
+        B, C, H, W = bev.shape
+        split = self._split()
+        t = ops.dwconv3x3_gelu(_f32(bev), self.refine[0].weight.detach().reshape(C, 9).contiguous(), self.refine[0].bias, split)
+        x32, _ = ops.linear(t, self._w(self.proj.weight), self.proj.bias, out_f32=True)
+        _, x = ops.layernorm(x32, self.norm_tokens.weight, self.norm_tokens.bias, self.norm_tokens.eps, split,
+                             post=self._pe_table(H, W, bev.device))
+        return x
+
+    def forward(self, bev: torch.Tensor) -> torch.Tensor:
+        self._guard(bev)
+        B, C, H, W = bev.shape
+        x = self.bev_tokens(bev)
+        # queries + per-view embedding (vat_lidar.py:259-270), broadcast over the batch
+        ve = self.view_embed.detach().float().repeat_interleave(self.nq_per_view, dim=0).contiguous()
+        q0 = ops.scale_add_rows(self.query.detach().float().contiguous(), ve)
+        q2 = q0.unsqueeze(0).expand(B, -1, -1).contiguous().view(B * self.n_queries, self.d_model)
+        for blk in self.blocks:
+            blk.precision = self.precision
+            q2 = blk.forward_tokens(q2, x, B, self.n_queries, H * W)
+        return _post_head(self, q2, self.final_ln, self.post).view(B, self.n_queries, self.d_model)
+
+
+class VATVision(_HipModule):
+    """[B, n_input_tokens, d_in] -> [B, n_input_tokens/compression_factor, d_model]."""
+
+    def __init__(self, d_in: int, d_model: int, n_input_tokens: int = 1536, compression_factor: int = 2, n_layers: int = 4,
+                 n_heads: int = 8, mlp_ratio: float = 4.0, dropout: float = 0.10, post_dropout: float = 0.10,
+                 use_per_view_query: bool = False, strict_per_view: bool = False):
+        super().__init__()
+        assert n_input_tokens % compression_factor == 0, \
+            f"n_input_tokens ({n_input_tokens}) must be divisible by compression_factor ({compression_factor})"
+        self.d_in, self.d_model = d_in, d_model
+        self.n_input_tokens, self.compression_factor = n_input_tokens, compression_factor
+        self.n_queries = n_input_tokens // compression_factor
+        feasible = NUM_VIEWS > 0 and self.n_queries >= NUM_VIEWS and self.n_queries % NUM_VIEWS == 0
+        if use_per_view_query and not feasible:
+            if strict_per_view:
+                raise ValueError(f"Per-view queries requested but not feasible: n_queries={self.n_queries}, NUM_VIEWS={NUM_VIEWS}. "
+                                 f"Either increase n_queries to be divisible by {NUM_VIEWS}, or set use_per_view_query=False, "
+                                 f"or set strict_per_view=False for auto-disable.")
+            print("[VATVision] Warning: use_per_view_query=True requested but not feasible:")
+            print(f"             n_queries={self.n_queries}, NUM_VIEWS={NUM_VIEWS}")
+            print("             Automatically disabling per-view queries.")
+            use_per_view_query = False
+        self.use_per_view_query = use_per_view_query
+        self.nq_per_view = self.n_queries // NUM_VIEWS if use_per_view_query else 0
+        self.query = nn.Parameter(torch.randn(self.n_queries, d_in) * 0.02)
+        if self.use_per_view_query:
+            self.view_query_embed = nn.Parameter(torch.zeros(NUM_VIEWS, d_in))
+            nn.init.trunc_normal_(self.view_query_embed, std=0.02)
+        else:
+            self.view_query_embed = None
+        d_ff = int(mlp_ratio * d_in)
+        self.blocks = nn.ModuleList([VATBlock(d_in, n_heads, d_ff, dropout) for _ in range(n_layers)])
+        self.final_ln = nn.LayerNorm(d_in)
+        self.post = nn.Sequential(nn.LayerNorm(d_in), nn.Linear(d_in, d_in), nn.GELU(), nn.Dropout(post_dropout),
+                                  nn.Linear(d_in, d_in))
+        self.proj = nn.Sequential(nn.LayerNorm(d_in), nn.Linear(d_in, d_model), nn.GELU(), nn.Dropout(dropout),
+                                  nn.Linear(d_model, d_model), nn.LayerNorm(d_model))
+
+    def forward(self, kv_tokens: torch.Tensor) -> torch.Tensor:
+        self._guard(kv_tokens)
+        B, N, D = kv_tokens.shape
+        assert N == self.n_input_tokens, f"Expected {self.n_input_tokens} input tokens, got {N}"
+        assert D == self.d_in, f"Expected d_in={self.d_in}, got {D}"
+        split = self._split()
+        kv = ops.cast(_f32(kv_tokens).view(B * N, D), split)
+        q0 = self.query.detach().float().contiguous()
+        if self.use_per_view_query and self.nq_per_view > 0:
+            q0 = ops.scale_add_rows(q0, self.view_query_embed.detach().float().repeat_interleave(self.nq_per_view, dim=0).contiguous())
+        q2 = q0.unsqueeze(0).expand(B, -1, -1).contiguous().view(B * self.n_queries, D)
+        for blk in self.blocks:
+            blk.precision = self.precision
+            q2 = blk.forward_tokens(q2, kv, B, self.n_queries, N)
+        q2 = _post_head(self, q2, self.final_ln, self.post)
+        _, hn = ops.layernorm(q2, self.proj[0].weight, self.proj[0].bias, self.proj[0].eps, split)
+        _, h1 = ops.linear(hn, self._w(self.proj[1].weight), self.proj[1].bias, gelu=True, out_bf=True)
+        y, _ = ops.linear(h1, self._w(self.proj[4].weight), self.proj[4].bias, out_f32=True)
+        out, _ = ops.layernorm(y, self.proj[5].weight, self.proj[5].bias, self.proj[5].eps, split, want_f32=True, want_bf=False)
+        return out.view(B, self.n_queries, self.d_model)
+
+
+class VisionAdapter(_HipModule):
+    """6 x [HW, d_in] -> [6*HW, d_in]: LayerNorm(t + view_embed[v]) per view, concatenated (eval: no dropout)."""
+
+    def __init__(self, d_in: int, dropout: float = 0.10):
+        super().__init__()
+        self.d_in = d_in
+        self.num_views = len(CAM_VIEWS)
+        self.norm = nn.LayerNorm(d_in)
+        self.dropout = nn.Dropout(dropout)
+        self.view_embed = nn.Parameter(torch.zeros(self.num_views, d_in), requires_grad=True)
+        nn.init.trunc_normal_(self.view_embed, std=0.02)
+
+    def forward(self, views_tokens: List[torch.Tensor]) -> torch.Tensor:
+        if len(views_tokens) != self.num_views:
+            raise ValueError(f"Expected {self.num_views} views in order {CAM_VIEWS}, got {len(views_tokens)}")
+        hw = None
+        for v_idx, t in enumerate(views_tokens):
+            if t.dim() != 2:
+                raise ValueError(f"Expected tensor of shape [HW, d_in] for view {v_idx}, got shape {tuple(t.shape)}")
+            if hw is None:
+                hw = t.shape[0]
+            elif t.shape[0] != hw:
+                raise ValueError(f"All views must have same HW. Got {hw} and {t.shape[0]}.")
+        self._guard(*views_tokens)
+        x = torch.cat([_f32(t) for t in views_tokens], dim=0)            # view-major rows: group v = rows v*hw..(v+1)*hw
+        out, _ = ops.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps, False, want_f32=True, want_bf=False,
+                               add=self.view_embed.detach().float().contiguous(), add_group=hw)
+        return out
+
+
+def sdp_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_mask: Optional[torch.Tensor] = None,
+                  precision: Optional[str] = None) -> torch.Tensor:
+    """[B,H,S,D] x3 (+ additive mask/bias [B,H,S,S]) -> [B,H,S,D] (deepencoder/clip_sdpa.py:50-66)."""
+    F.require_cuda(q, k, v, attn_mask)
+    B, H, S, D = q.shape
+    Sk = k.shape[2]
+    split = (precision or ops.default_precision()) == "bf16x3"
+    qb, kb, vb = (ops.cast(_f32(t).view(B * H * t.shape[2], D), split) for t in (q, k, v))
+    bias = None if attn_mask is None else _f32(attn_mask.expand(B, H, S, Sk))
+    # output addressed as [B, S, H*D] by the ABI; request [B,H,S,D] through the strides instead
+    import ctypes
+    oh, ol = ops._bf_empty((B * H * S, D), q.device, split)
+    L = F.lib()
+    L.lvq_attention_workspace_bytes.restype = ctypes.c_size_t
+    nbytes = L.lvq_attention_workspace_bytes(F.cint(B), F.cint(H), F.cint(S), F.cint(Sk), F.cint(D), F.cint(3 if split else 1))
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=q.device)
+    rc = L.lvq_attention_bf16(F.ptr(qb[0]), F.ptr(qb[1]), F.ptr(kb[0]), F.ptr(kb[1]), F.ptr(vb[0]), F.ptr(vb[1]), F.ptr(bias),
+                              F.cint(B), F.cint(H), F.cint(H), F.cint(S), F.cint(Sk), F.cint(D),
+                              F.i64(H * S * D), F.i64(D), F.i64(S * D), F.i64(H * Sk * D), F.i64(D), F.i64(Sk * D),
+                              F.i64(H * Sk * D), F.i64(D), F.i64(Sk * D), F.i64(H * S * D), F.i64(D), F.i64(S * D),
+                              F.cfloat(1.0 / math.sqrt(D)), F.cint(0), F.ptr(oh), F.ptr(ol), F.ptr(ws), F.csize(ws.numel()),
+                              F.stream_ptr(q.device))
+    F.check(rc, "lvq_attention_bf16")
+    return ops.to_f32((oh, ol)).view(B, H, S, D)
+
+
+class MlpProjectorLinear(_HipModule):
+    """deepencoder/build_linear.py:18-19,156 `MlpProjector(projector_type="linear")`: one nn.Linear named `layers`."""
+
+    def __init__(self, input_dim: int, n_embed: int):
+        super().__init__()
+        self.layers = nn.Linear(input_dim, n_embed)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        self._guard(x)
+        shp = x.shape
+        y, _ = ops.linear(ops.cast(_f32(x).view(-1, shp[-1]), self._split()), self._w(self.layers.weight), self.layers.bias,
+                          out_f32=True)
+        return y.view(*shp[:-1], -1)
+
+
+def deepencoder_fuse(projector: MlpProjectorLinear, clip_tokens: torch.Tensor, sam_feat: torch.Tensor) -> torch.Tensor:
+    """deepencoder_infer.py:505-511: cat(clip[:,1:], sam.flatten(2).permute(0,2,1)) -> projector."""
+    sam = sam_feat.flatten(2).permute(0, 2, 1)
+    return projector(torch.cat((clip_tokens[:, 1:], sam), dim=-1).contiguous())

@@ -1,0 +1,158 @@
+"""Thin Python wrappers over the fusion-side C ABI (include/lvq.h): argument marshalling only.
+
+A "BF" value is a pair (hi, lo) of torch.bfloat16 tensors; lo is None in plain-bf16 mode and the
+residual x - hi in bf16x3 mode (see include/lvq.h "Precision modes").
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+
+from . import _ffi as F
+
+BF = Tuple[torch.Tensor, Optional[torch.Tensor]]
+
+PRECISIONS = ("bf16", "bf16x3")
+_default_precision = os.environ.get("LVQ_PRECISION", "bf16x3")
+assert _default_precision in PRECISIONS
+
+
+def default_precision() -> str:
+    return _default_precision
+
+
+def set_default_precision(p: str):
+    global _default_precision
+    if p not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS}")
+    _default_precision = p
+
+
+def _bf_empty(shape, dev, split: bool) -> BF:
+    hi = torch.empty(shape, dtype=torch.bfloat16, device=dev)
+    return hi, (torch.empty(shape, dtype=torch.bfloat16, device=dev) if split else None)
+
+
+def cast(x: torch.Tensor, split: bool) -> BF:
+    F.require_cuda(x)
+    assert x.dtype == torch.float32
+    hi, lo = _bf_empty(x.shape, x.device, split)
+    F.check(F.lib().lvq_cast_bf16(F.ptr(x), F.i64(x.numel()), F.ptr(hi), F.ptr(lo), F.stream_ptr(x.device)), "lvq_cast_bf16")
+    return hi, lo
+
+
+def to_f32(x: BF, alpha: float = 1.0) -> torch.Tensor:
+    hi, lo = x
+    out = torch.empty(hi.shape, dtype=torch.float32, device=hi.device)
+    F.check(F.lib().lvq_bf16_to_f32(F.ptr(hi), F.ptr(lo), F.i64(hi.numel()), F.cfloat(alpha), F.ptr(out),
+                                    F.stream_ptr(hi.device)), "lvq_bf16_to_f32")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor], eps: float, split: bool,
+              want_f32: bool = False, want_bf: bool = True, add: Optional[torch.Tensor] = None, add_group: int = 1,
+              post: Optional[torch.Tensor] = None):
+    """x [rows, d] fp32 -> (y_f32 | None, BF | None)."""
+    F.require_cuda(x, gamma, beta, add, post)
+    rows, d = x.shape
+    y32 = torch.empty_like(x) if want_f32 else None
+    hi, lo = _bf_empty(x.shape, x.device, split) if want_bf else (None, None)
+    rc = F.lib().lvq_layernorm(F.ptr(x), F.ptr(add), F.cint(add.shape[0] if add is not None else 0), F.cint(add_group),
+                               F.ptr(gamma), F.ptr(beta), F.cfloat(eps), F.i64(rows), F.cint(d), F.ptr(post),
+                               F.i64(post.shape[0] if post is not None else 0), F.ptr(y32), F.ptr(hi), F.ptr(lo),
+                               F.stream_ptr(x.device))
+    F.check(rc, "lvq_layernorm")
+    return y32, ((hi, lo) if want_bf else None)
+
+
+def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, split: bool) -> BF:
+    rows, d = x.shape
+    hi, lo = _bf_empty(x.shape, x.device, split)
+    rc = F.lib().lvq_rmsnorm(F.ptr(x), F.ptr(gamma), F.cfloat(eps), F.i64(rows), F.cint(d), F.ptr(None), F.ptr(hi), F.ptr(lo),
+                             F.stream_ptr(x.device))
+    F.check(rc, "lvq_rmsnorm")
+    return hi, lo
+
+
+def linear(a: BF, w: BF, bias: Optional[torch.Tensor] = None, *, gelu: bool = False, alpha: float = 1.0,
+           residual: Optional[torch.Tensor] = None, rowtab: Optional[torch.Tensor] = None, out_f32: bool = False,
+           out_bf: bool = False, w_rows: Optional[Tuple[int, int]] = None):
+    """y = a @ w[r0:r1].T (+bias[r0:r1]) ... ; a hi [M,K], w hi [N,K].  Returns (y_f32 | None, BF | None)."""
+    ah, al = a
+    wh, wl = w
+    m, k = ah.shape
+    r0, r1 = w_rows if w_rows is not None else (0, wh.shape[0])
+    n = r1 - r0
+    assert wh.shape[1] == k and (al is None) == (wl is None)
+    dev = ah.device
+    split = al is not None
+    c32 = torch.empty((m, n), dtype=torch.float32, device=dev) if out_f32 else None
+    ch, cl = _bf_empty((m, n), dev, split) if out_bf else (None, None)
+    wo = r0 * k * 2  # byte offset of the weight row slice
+    bo = r0 * 4
+    import ctypes
+    rc = F.lib().lvq_gemm_bf16(
+        F.ptr(ah), F.ptr(al), ctypes.c_void_p(wh.data_ptr() + wo), ctypes.c_void_p(wl.data_ptr() + wo if split else 0),
+        ctypes.c_void_p(bias.data_ptr() + bo if bias is not None else 0), F.ptr(residual), F.ptr(rowtab),
+        F.i64(rowtab.shape[0] if rowtab is not None else 0), F.cfloat(alpha), F.cint(1 if gelu else 0), F.i64(m), F.cint(n),
+        F.cint(k), F.i64(k), F.i64(k), F.i64(n), F.cint(1), F.i64(0), F.i64(0), F.i64(0), F.ptr(c32), F.ptr(ch), F.ptr(cl),
+        F.stream_ptr(dev))
+    F.check(rc, f"lvq_gemm_bf16 (m={m}, n={n}, k={k})")
+    return c32, ((ch, cl) if out_bf else None)
+
+
+_ATT_WS = {}
+
+
+def attention(q: BF, k: BF, v: BF, *, batch: int, n_heads: int, n_kv_heads: int, nq: int, nkv: int, dh: int,
+              q_strides, k_strides, v_strides, scale: float, bias: Optional[torch.Tensor] = None, causal: bool = False) -> BF:
+    """q/k/v: BF views (possibly column slices of packed projections); *_strides = (batch, row, head) in elements.
+    Returns BF [batch*nq, n_heads*dh]."""
+    import ctypes
+    qh, ql = q
+    dev = qh.device
+    split = ql is not None
+    oh, ol = _bf_empty((batch * nq, n_heads * dh), dev, split)
+    L = F.lib()
+    L.lvq_attention_workspace_bytes.restype = ctypes.c_size_t
+    nbytes = L.lvq_attention_workspace_bytes(F.cint(batch), F.cint(n_heads), F.cint(nq), F.cint(nkv), F.cint(dh),
+                                             F.cint(3 if split else 1))
+    key = (dev.index, "attn")
+    ws = _ATT_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _ATT_WS[key] = ws
+    d = n_heads * dh
+    rc = L.lvq_attention_bf16(
+        F.ptr(qh), F.ptr(ql), F.ptr(k[0]), F.ptr(k[1]), F.ptr(v[0]), F.ptr(v[1]), F.ptr(bias), F.cint(batch), F.cint(n_heads),
+        F.cint(n_kv_heads), F.cint(nq), F.cint(nkv), F.cint(dh),
+        F.i64(q_strides[0]), F.i64(q_strides[1]), F.i64(q_strides[2]),
+        F.i64(k_strides[0]), F.i64(k_strides[1]), F.i64(k_strides[2]),
+        F.i64(v_strides[0]), F.i64(v_strides[1]), F.i64(v_strides[2]),
+        F.i64(nq * d), F.i64(d), F.i64(dh), F.cfloat(scale), F.cint(1 if causal else 0), F.ptr(oh), F.ptr(ol),
+        F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
+    F.check(rc, f"lvq_attention_bf16 (B={batch}, H={n_heads}, nq={nq}, nkv={nkv}, dh={dh})")
+    return oh, ol
+
+
+def dwconv3x3_gelu(bev: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], split: bool) -> BF:
+    """bev [B,C,H,W] fp32 -> tokens BF [B*H*W, C]."""
+    F.require_cuda(bev, w, b)
+    B, C, H, W = bev.shape
+    hi, lo = _bf_empty((B * H * W, C), bev.device, split)
+    rc = F.lib().lvq_dwconv3x3_gelu(F.ptr(bev), F.ptr(w), F.ptr(b), F.cint(B), F.cint(C), F.cint(H), F.cint(W), F.ptr(hi),
+                                    F.ptr(lo), F.stream_ptr(bev.device))
+    F.check(rc, "lvq_dwconv3x3_gelu")
+    return hi, lo
+
+
+def scale_add_rows(x: torch.Tensor, add: Optional[torch.Tensor], alpha: float = 1.0) -> torch.Tensor:
+    F.require_cuda(x, add)
+    rows, d = x.shape
+    out = torch.empty_like(x)
+    rc = F.lib().lvq_scale_add_rows(F.ptr(x), F.ptr(add), F.i64(add.shape[0] if add is not None else 0), F.cfloat(alpha),
+                                    F.i64(rows), F.cint(d), F.ptr(out), F.stream_ptr(x.device))
+    F.check(rc, "lvq_scale_add_rows")
+    return out

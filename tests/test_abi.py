@@ -1,0 +1,93 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every
+symbol include/lvq.h declares; pure-host entry points behave; the Python host mirrors the reference's
+plugin interfaces (names, constructor keywords, state_dict keys)."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from lidar_vision_vqa_amd import _ffi
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_ffi.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _ffi.lib()
+
+
+def test_exports_every_declared_symbol(lib):
+    names = _ffi.declared_symbols()
+    assert len(names) >= 20
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_host_only_entry_points(lib):
+    assert b"gfx950" in lib.lvq_version()
+    assert lib.lvq_strerror(0) == b"ok" and b"workspace" in lib.lvq_strerror(-2)
+    n = lib.lvq_voxelize_hard_workspace_bytes(ctypes.c_int64(32768), ctypes.c_int(1))
+    assert 1 << 20 < n < 1 << 24
+    g = (ctypes.c_int32 * 3)(1024, 1024, 40)
+    assert lib.lvq_voxelize_dynamic_workspace_bytes(ctypes.c_int64(32768), ctypes.c_int(8), g, ctypes.c_int(3)) > 0
+    # 64 scenes x 1440x1440x40 cells >= 2^31 keys: refused (the reference wraps int32 silently)
+    g2 = (ctypes.c_int32 * 3)(1440, 1440, 40)
+    assert lib.lvq_voxelize_dynamic_workspace_bytes(ctypes.c_int64(10), ctypes.c_int(64), g2, ctypes.c_int(3)) == 0
+
+
+def test_no_cpu_fallback():
+    """The product path fails loudly on CPU tensors instead of silently computing elsewhere."""
+    from lidar_vision_vqa_amd import fusion, lidar
+    m = fusion.VATBlock(96, 4, 384, 0.1).eval()
+    with pytest.raises(_ffi.LvqError), torch.no_grad():
+        m(torch.zeros(1, 4, 96), torch.zeros(1, 5, 96))
+    with pytest.raises(_ffi.LvqError):
+        lidar.MeanVFE(None, 4)(dict(voxels=torch.zeros(2, 3, 4), voxel_num_points=torch.ones(2)))
+
+
+def test_module_api_mirrors_reference():
+    from lidar_vision_vqa_amd import fusion, lidar
+    # registries with the reference's NAME strings (vfe/__init__.py:9-18)
+    assert set(lidar.__all__) >= {"MeanVFE", "PillarVFE", "DynMeanVFE", "DynPillarVFE", "DynamicPillarVFESimple2D", "DynamicVoxelVFE"}
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+    p = lidar.__all__["PillarVFE"](model_cfg=Cfg(USE_NORM=True, WITH_DISTANCE=False, USE_ABSLOTE_XYZ=True, NUM_FILTERS=[64]),
+                                   num_point_features=4, voxel_size=[0.2, 0.2, 8], point_cloud_range=[-51.2, -51.2, -5, 51.2, 51.2, 3],
+                                   grid_size=[512, 512, 1], depth_downsample_factor=None)
+    assert p.get_output_feature_dim() == 64
+    assert set(p.state_dict()) == {"pfn_layers.0.linear.weight", "pfn_layers.0.norm.weight", "pfn_layers.0.norm.bias",
+                                   "pfn_layers.0.norm.running_mean", "pfn_layers.0.norm.running_var",
+                                   "pfn_layers.0.norm.num_batches_tracked"}
+    assert tuple(p.state_dict()["pfn_layers.0.linear.weight"].shape) == (64, 10)
+    v = fusion.VATLiDAR(c_in=128, d_model=96, n_queries=12, n_layers=2, n_heads=4)
+    keys = set(v.state_dict())
+    for k in ("view_embed", "query", "refine.0.weight", "refine.0.bias", "proj.weight", "proj.bias", "norm_tokens.weight",
+              "geo_mlp.0.weight", "geo_mlp.2.bias", "final_ln.weight", "post.0.weight", "post.1.weight", "post.4.bias",
+              "blocks.1.ca.in_proj_weight", "blocks.0.sa.out_proj.bias", "blocks.1.mlp.3.weight"):
+        assert k in keys, k
+    assert tuple(v.state_dict()["blocks.0.ca.in_proj_weight"].shape) == (288, 96)
+    with pytest.raises(AssertionError):
+        fusion.VATLiDAR(c_in=16, d_model=96, n_queries=256)        # vat_lidar.py:75: n_queries % 6 == 0
+    vv = fusion.VATVision(d_in=128, d_model=96, n_input_tokens=48, compression_factor=2, n_layers=1, n_heads=4, use_per_view_query=True)
+    assert "view_query_embed" in vv.state_dict() and vv.n_queries == 24
+    with pytest.raises(ValueError):
+        fusion.VATVision(d_in=128, d_model=96, n_input_tokens=50, compression_factor=2, use_per_view_query=True, strict_per_view=True)
+    va = fusion.VisionAdapter(128)
+    assert set(va.state_dict()) == {"view_embed", "norm.weight", "norm.bias"}
+    with pytest.raises(ValueError):
+        va([torch.zeros(4, 128)] * 5)
+
+
+def test_default_init_matches_reference_rng_order():
+    """Same torch.manual_seed -> same default-initialised weights as torch's own containers built in the
+    reference's order (vat_blocks.py:17-34): checkpoints AND fresh inits are interchangeable."""
+    from lidar_vision_vqa_amd import fusion
+    import torch.nn as nn
+    torch.manual_seed(123)
+    ours = fusion.VATBlock(64, 4, 128, 0.1)
+    torch.manual_seed(123)
+    ln1 = nn.LayerNorm(64); sa = nn.MultiheadAttention(64, 4, dropout=0.1, batch_first=True)
+    assert torch.equal(ours.sa.in_proj_weight, sa.in_proj_weight)

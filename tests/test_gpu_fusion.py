@@ -1,0 +1,309 @@
+"""GPU parity tests, fusion side: HIP kernels (through the C ABI) vs
+  (1) exact-arithmetic unit references: operands pre-rounded to bf16, reference in fp64 on the host ->
+      only accumulation order differs, so indexing / layout bugs cannot hide behind a tolerance;
+  (2) the committed goldens of the UNMODIFIED reference modules (tests/golden/*.npz);
+  (3) the CPU oracle at the BASELINE shapes.
+Tolerances (written here, per north_star): fused tokens within 1e-3 abs of the fp32 CPU reference in
+the bf16x3 mode; the plain-bf16 mode is bounded by operand rounding: 2e-2 * max|ref| (DESIGN.md Numerics)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+from lidar_vision_vqa_amd import synth  # noqa: E402
+from oracle import vat_oracle as VO  # noqa: E402
+
+DEV = "cuda:0"
+TOL_X3 = 1e-3          # north_star: fused tokens within 1e-3 fp32
+REL_BF16 = 2e-2        # plain bf16 operands (2^-9 rounding per operand, up to ~20 stages + LayerNorms): relative to max|ref|
+
+
+def fusion():
+    from lidar_vision_vqa_amd import fusion as f
+    return f
+
+
+def ops():
+    from lidar_vision_vqa_amd import ops as o
+    return o
+
+
+def bf_round(x: torch.Tensor) -> torch.Tensor:
+    return x.to(torch.bfloat16).float()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------------
+# unit kernels
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,k", [(64, 64, 64), (128, 128, 128), (200, 136, 72), (1, 8, 8), (333, 768, 768),
+                                   (4096, 1536, 768), (130, 3072, 768), (196, 64, 2048), (1000, 776, 8)])
+@pytest.mark.parametrize("split", [False, True])
+def test_gemm_exact(m, n, k, split):
+    o = ops()
+    a = torch.from_numpy(synth.randn((m, k), 1)).to(DEV)
+    w = torch.from_numpy(synth.randn((n, k), 2, 0.1)).to(DEV)
+    bias = torch.from_numpy(synth.randn((n,), 3)).to(DEV)
+    res = torch.from_numpy(synth.randn((m, n), 4)).to(DEV)
+    if not split:
+        a, w = bf_round(a), bf_round(w)
+    c32, cb = o.linear(o.cast(a, split), o.cast(w, split), bias, residual=res, out_f32=True, out_bf=True)
+    ref = a.double().cpu() @ w.double().cpu().t() + bias.double().cpu() + res.double().cpu()
+    err = (c32.double().cpu() - ref).abs().max().item()
+    tol = (2e-5 if not split else 2e-4) * max(1.0, ref.abs().max().item())   # split: lo*lo term dropped (2^-16 rel)
+    assert err < tol, err
+    back = o.to_f32(cb).double().cpu()
+    assert (back - ref).abs().max().item() < (tol if split else 1e-2 * ref.abs().max().item())
+
+
+def test_gemm_epilogues_and_slices():
+    o = ops()
+    m, n, k = 300, 192, 96
+    a = bf_round(torch.from_numpy(synth.randn((m, k), 5))).to(DEV)
+    w = bf_round(torch.from_numpy(synth.randn((3 * n, k), 6, 0.2))).to(DEV)
+    bias = torch.from_numpy(synth.randn((3 * n,), 7)).to(DEV)
+    tab = torch.from_numpy(synth.randn((50, n), 8)).to(DEV)
+    y, _ = o.linear(o.cast(a, False), o.cast(w, False), bias, gelu=True, alpha=0.5, rowtab=tab, out_f32=True, w_rows=(n, 2 * n))
+    z = a.double().cpu() @ w.double().cpu()[n:2 * n].t() + bias.double().cpu()[n:2 * n]
+    ref = 0.5 * (0.5 * z * (1 + torch.erf(z / math.sqrt(2)))) + tab.double().cpu()[torch.arange(m) % 50]
+    assert (y.double().cpu() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("rows,d", [(1, 8), (7, 96), (1000, 768), (130, 2048), (5, 896)])
+def test_layernorm(rows, d):
+    o = ops()
+    x = torch.from_numpy(synth.randn((rows, d), 11, 3.0)).to(DEV) + 1.5
+    g = torch.from_numpy(synth.randn((d,), 12)).to(DEV)
+    b = torch.from_numpy(synth.randn((d,), 13)).to(DEV)
+    post = torch.from_numpy(synth.randn((3, d), 14)).to(DEV)
+    y32, ybf = o.layernorm(x, g, b, 1e-5, True, want_f32=True, post=post)
+    ref = torch.nn.functional.layer_norm(x.double().cpu(), (d,), g.double().cpu(), b.double().cpu(), 1e-5) + post.double().cpu()[torch.arange(rows) % 3]
+    assert (y32.double().cpu() - ref).abs().max().item() < 2e-5
+    assert (o.to_f32(ybf).double().cpu() - ref).abs().max().item() < 2e-4
+
+
+ATT_CASES = [
+    # B, H, Hkv, nq, nkv, dh, bias, causal
+    (1, 2, 2, 16, 64, 64, False, False),
+    (2, 4, 4, 50, 50, 64, False, False),
+    (1, 12, 12, 49, 49, 64, True, False),       # SAM window attention with rel-pos bias
+    (2, 3, 3, 100, 196, 32, False, False),
+    (1, 2, 2, 70, 130, 112, False, False),      # head_dim 112 = 896/8
+    (1, 2, 2, 33, 77, 96, True, False),
+    (1, 8, 8, 64, 300, 128, False, False),
+    (1, 4, 2, 40, 40, 32, False, True),         # GQA + causal (stand-in head)
+    (2, 4, 1, 37, 37, 64, False, True),
+    (1, 2, 2, 24, 100, 448, False, False),      # split path (reference default vat_heads=2, d=896)
+    (1, 2, 2, 12, 60, 1024, False, False),      # split path (vision_heads=2, d_in=2048)
+    (1, 2, 2, 30, 30, 256, False, True),
+]
+
+
+@pytest.mark.parametrize("B,H,Hkv,nq,nkv,dh,use_bias,causal", ATT_CASES)
+@pytest.mark.parametrize("split", [False, True])
+def test_attention(B, H, Hkv, nq, nkv, dh, use_bias, causal, split):
+    o = ops()
+    q = torch.from_numpy(synth.randn((B, nq, H, dh), 21)).to(DEV)
+    k = torch.from_numpy(synth.randn((B, nkv, Hkv, dh), 22)).to(DEV)
+    v = torch.from_numpy(synth.randn((B, nkv, Hkv, dh), 23)).to(DEV)
+    if not split:
+        q, k, v = bf_round(q), bf_round(k), bf_round(v)
+    bias = torch.from_numpy(synth.randn((B, H, nq, nkv), 24)).to(DEV) if use_bias else None
+    qb, kb, vb = (o.cast(t.reshape(-1, t.shape[-2] * dh), split) for t in (q, k, v))
+    out = o.attention(qb, kb, vb, batch=B, n_heads=H, n_kv_heads=Hkv, nq=nq, nkv=nkv, dh=dh,
+                      q_strides=(nq * H * dh, H * dh, dh), k_strides=(nkv * Hkv * dh, Hkv * dh, dh),
+                      v_strides=(nkv * Hkv * dh, Hkv * dh, dh), scale=1.0 / math.sqrt(dh), bias=bias, causal=causal)
+    got = o.to_f32(out).double().cpu().view(B, nq, H, dh)
+    qd, kd, vd = (t.double().cpu().transpose(1, 2) for t in (q, k, v))
+    kd = kd.repeat_interleave(H // Hkv, dim=1)
+    vd = vd.repeat_interleave(H // Hkv, dim=1)
+    s = qd @ kd.transpose(-1, -2) / math.sqrt(dh)
+    if bias is not None:
+        s = s + bias.double().cpu()
+    if causal:
+        i = torch.arange(nq).view(-1, 1)
+        j = torch.arange(nkv).view(1, -1)
+        s = s.masked_fill(j > i + nkv - nq, float("-inf"))
+    ref = (torch.softmax(s, -1) @ vd).transpose(1, 2)
+    err = (got - ref).abs().max().item()
+    # plain mode: P and the output are rounded to bf16 (2^-9); split mode: ~1e-5
+    assert err < (2e-2 if not split else 2e-4), err
+
+
+def test_dwconv3x3_gelu():
+    o = ops()
+    B, C, H, W = 2, 40, 21, 70
+    x = torch.from_numpy(synth.randn((B, C, H, W), 31)).to(DEV)
+    w = torch.from_numpy(synth.randn((C, 1, 3, 3), 32, 0.3)).to(DEV)
+    b = torch.from_numpy(synth.randn((C,), 33, 0.1)).to(DEV)
+    t = o.dwconv3x3_gelu(x, w.reshape(C, 9).contiguous(), b, True)
+    ref = torch.nn.functional.gelu(torch.nn.functional.conv2d(x.cpu(), w.cpu(), b.cpu(), padding=1, groups=C))
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * W, C)
+    assert (o.to_f32(t).cpu() - ref).abs().max().item() < 1e-4
+
+
+# ------------------------------------------------------------------------------------------------
+# modules vs goldens of the imported reference
+# ------------------------------------------------------------------------------------------------
+def check(out: torch.Tensor, ref: np.ndarray, prec: str, scale: float = 1.0):
+    ref_t = torch.from_numpy(ref)
+    err = (out.float().cpu() - ref_t).abs().max().item() * scale
+    if prec == "bf16x3":
+        assert err < TOL_X3, f"{prec}: max abs err {err}"
+    else:
+        assert err < REL_BF16 * max(1.0, ref_t.abs().max().item()), f"{prec}: max abs err {err}"
+    return err
+
+
+@pytest.mark.parametrize("name", list(cases.VAT_BLOCK_CASES))
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_vat_block_golden(name, prec):
+    c = cases.VAT_BLOCK_CASES[name]
+    m = fusion().VATBlock(c["d"], c["h"], c["dff"], 0.1).to(DEV).eval()
+    synth.load_seeded(m, c["seed"])
+    m.precision = prec
+    q, kv = dev(synth.randn((c["B"], c["Nq"], c["d"]), c["seed"] + 1000)), dev(synth.randn((c["B"], c["Nk"], c["d"]), c["seed"] + 2000))
+    with torch.no_grad():
+        out = m(q, kv)
+    assert tuple(out.shape) == (c["B"], c["Nq"], c["d"]) and bool(torch.isfinite(out).all())
+    check(out, golden("vat_block_" + name)["out"], prec)
+
+
+def test_vat_block_api_surface():
+    """state_dict keys == the reference's; train mode / autograd are refused loudly."""
+    f = fusion()
+    m = f.VATBlock(96, 4, 384, 0.1)
+    keys = set(m.state_dict().keys())
+    expect = set()
+    for a in ("sa", "ca"):
+        expect |= {f"{a}_ln.weight", f"{a}_ln.bias", f"{a}.in_proj_weight", f"{a}.in_proj_bias", f"{a}.out_proj.weight", f"{a}.out_proj.bias"}
+    expect |= {"mlp_ln.weight", "mlp_ln.bias", "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias"}
+    assert keys == expect
+    m = m.to(DEV)
+    q, kv = torch.zeros(1, 6, 96, device=DEV), torch.zeros(1, 5, 96, device=DEV)
+    with pytest.raises(Exception):
+        m.train()(q, kv)
+    with pytest.raises(Exception):
+        m.eval()(q, kv)                      # grad enabled + trainable params
+    with pytest.raises(Exception), torch.no_grad():
+        m.eval()(q.cpu(), kv.cpu())          # no CPU fallback
+
+
+@pytest.mark.parametrize("name", list(cases.VAT_LIDAR_CASES))
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_vat_lidar_golden(name, prec):
+    c = cases.VAT_LIDAR_CASES[name]
+    m = fusion().VATLiDAR(c["c_in"], c["d"], c["nq"], c["L"], c["h"]).to(DEV).eval()
+    synth.load_seeded(m, c["seed"])
+    m.precision = prec
+    g = golden("vat_lidar_" + name)
+    geom, sid = m._grid(c["H"], c["W"], torch.device(DEV))
+    assert np.array_equal(sid.cpu().numpy().astype(np.int32), g["sid"])      # sector ids: bit-exact
+    assert len(torch.unique(sid)) == 6
+    assert m._grid(c["H"], c["W"], torch.device(DEV))[0] is geom                # cache-stable (test_vat_lidar.py:188-197)
+    with torch.no_grad():
+        out = m(dev(synth.randn((c["B"], c["c_in"], c["H"], c["W"]), c["seed"] + 1000)))
+    assert tuple(out.shape) == (c["B"], c["nq"], c["d"])
+    check(out, g["out"], prec)
+
+
+@pytest.mark.parametrize("name", list(cases.VAT_VISION_CASES))
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_vat_vision_golden(name, prec):
+    c = cases.VAT_VISION_CASES[name]
+    m = fusion().VATVision(c["d_in"], c["d_model"], c["n_in"], c["cf"], c["L"], c["h"], use_per_view_query=c["per_view"]).to(DEV).eval()
+    synth.load_seeded(m, c["seed"])
+    m.precision = prec
+    with torch.no_grad():
+        out = m(dev(synth.randn((c["B"], c["n_in"], c["d_in"]), c["seed"] + 1000)))
+    check(out, golden("vat_vision_" + name)["out"], prec)
+    with pytest.raises(AssertionError), torch.no_grad():
+        m(torch.zeros(1, c["n_in"] + 1, c["d_in"], device=DEV))                 # vat_vision.py:162-165
+
+
+@pytest.mark.parametrize("name", list(cases.VISION_ADAPTER_CASES))
+def test_vision_adapter_golden(name):
+    c = cases.VISION_ADAPTER_CASES[name]
+    m = fusion().VisionAdapter(c["d_in"], 0.1).to(DEV).eval()
+    synth.load_seeded(m, c["seed"])
+    views = [dev(synth.randn((c["hw"], c["d_in"]), c["seed"] + 100 + v)) for v in range(6)]
+    with torch.no_grad():
+        out = m(views)
+    ref = golden("vision_adapter_" + name)["out"]
+    assert tuple(out.shape) == ref.shape
+    assert np.abs(out.cpu().numpy() - ref).max() < 2e-5                        # fp32 LayerNorm: no bf16 involved
+    with pytest.raises(ValueError):
+        m(views[:5])
+    with pytest.raises(ValueError):
+        m([v.unsqueeze(0) for v in views])
+    with pytest.raises(ValueError):
+        m(views[:5] + [views[5][:-1]])
+
+
+@pytest.mark.parametrize("name", list(cases.SDPA_CASES))
+def test_sdp_attention_golden(name):
+    c = cases.SDPA_CASES[name]
+    shp = (c["B"], c["H"], c["S"], c["D"])
+    q, k, v = (dev(synth.randn(shp, c["seed"] + i)) for i in range(3))
+    mask = dev(synth.randn((c["B"], c["H"], c["S"], c["S"]), c["seed"] + 3)) if c["mask"] else None
+    out = fusion().sdp_attention(q, k, v, mask, precision="bf16x3")
+    assert np.abs(out.cpu().numpy() - golden("sdpa_" + name)["out"]).max() < TOL_X3
+
+
+def test_deepencoder_fuse_golden():
+    f = fusion()
+    proj = f.MlpProjectorLinear(256, 192).to(DEV).eval()
+    synth.load_seeded(proj, 91)
+    proj.precision = "bf16x3"
+    with torch.no_grad():
+        out = f.deepencoder_fuse(proj, dev(synth.randn((1, 17, 128), 92)), dev(synth.randn((1, 128, 4, 4), 93)))
+    assert np.abs(out.cpu().numpy() - golden("deepencoder_fuse")["out"]).max() < TOL_X3
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE shapes vs the CPU oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Nq,Nk", [(1, 576, 196), (2, 256, 576), (1, 4096, 196)])
+def test_cross_attention_baseline_shapes(B, Nq, Nk):
+    """ca sub-path (vat_blocks.py:42) at d=768, h=12: (576,196) resampled tokens x patches, cfg-5
+    (256,576), and a slice of the '32k pts x 196 patches' headline shape."""
+    d, h = 768, 12
+    m = fusion().VATBlock(d, h, 4 * d, 0.1).to(DEV).eval()
+    synth.load_seeded(m, 401)
+    q, kv = dev(synth.randn((B, Nq, d), 402)), dev(synth.randn((B, Nk, d), 403))
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    qc, kvc = q.cpu(), kv.cpu()
+    ref = qc + VO.mha(VO.layer_norm(qc, sd["ca_ln.weight"], sd["ca_ln.bias"]), kvc, sd, "ca.", h)
+    for prec in ("bf16x3", "bf16"):
+        m.precision = prec
+        with torch.no_grad():
+            out = m.cross_attention(q, kv)
+        check(out, ref.numpy(), prec)
+
+
+def test_full_headline_shape_properties():
+    """(B,Nq,Nkv,d,h) = (1,32768,196,768,12): size-independent properties instead of a CPU oracle run:
+    (i) row-permutation equivariance in q, (ii) invariance to a permutation of the kv tokens (softmax over a
+    set), (iii) a 512-row slice equals the same rows computed alone."""
+    d, h = 768, 12
+    m = fusion().VATBlock(d, h, 4 * d, 0.1).to(DEV).eval()
+    synth.load_seeded(m, 411)
+    m.precision = "bf16"
+    q, kv = dev(synth.randn((1, 32768, d), 412)), dev(synth.randn((1, 196, d), 413))
+    with torch.no_grad():
+        full = m.cross_attention(q, kv)
+        perm = torch.randperm(32768, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+        assert torch.equal(m.cross_attention(q[:, perm], kv), full[:, perm])
+        kperm = torch.randperm(196, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+        assert (m.cross_attention(q, kv[:, kperm]) - full).abs().max().item() < 2e-2
+        assert torch.equal(m.cross_attention(q[:, 1000:1512], kv), full[:, 1000:1512])
+    assert bool(torch.isfinite(full).all())
