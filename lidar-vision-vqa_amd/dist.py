@@ -1,0 +1,84 @@
+"""Scene-parallel data parallelism: one process per GPU, RCCL over xGMI (`backend="nccl"` IS RCCL on ROCm).
+
+The forward path has NO exchange step: each scene's points, BEV, image tokens and prompt are
+private and the weights are replicated, so scenes are sharded `scene i -> rank i mod world` (what the
+reference's DistributedSampler does, trainer.py:202-206) with no data-path collective.  The only
+communication is ONE all-reduce(SUM) per step over a single fused fp32 buffer [payload | scene count]
+(semantics of pcdet/utils/commu_utils.py:148-168 `all_reduce(..., average=True)`): a few KB, i.e.
+latency-bound on xGMI, so everything is fused into one buffer / one collective.
+
+Mirrors encoder-decoder/training/utils/distributed.py:7-26 (`get_dist_info`, `init_dist_if_needed`).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def get_dist_info() -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from the torchrun environment (distributed.py:7-12)."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init_dist_if_needed(backend: str | None = None) -> Tuple[int, int, int]:
+    """init_process_group(env://) iff WORLD_SIZE > 1 and not yet initialised (distributed.py:15-21).
+    Backend: RCCL ("nccl") when a GPU is visible, gloo otherwise (CPU tests)."""
+    rank, local_rank, world = get_dist_info()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def barrier():
+    if is_dist():
+        dist.barrier()
+
+
+def finalize():
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def shard_scenes(n_scenes: int, rank: int, world: int) -> List[int]:
+    """Scene ids owned by `rank`: i mod world == rank (DistributedSampler order without shuffling)."""
+    return list(range(rank, n_scenes, world))
+
+
+def max_over_ranks(x: float, device=None) -> float:
+    if not is_dist():
+        return x
+    t = torch.tensor([x], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def reduce_step(per_scene: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
+    """Fill buf = [sum over scenes and tokens of per_scene (d) | n_scenes] and all-reduce(SUM) it once.
+    per_scene [S, n, d] (fused tokens, or answer logits once the head is attached).  After the call
+    buf[:-1] / buf[-1] is the global per-scene mean.  Stream-ordered; returns buf."""
+    S = per_scene.shape[0]
+    buf[:-1] = per_scene.sum(dim=(0, 1))
+    buf[-1] = float(S)
+    if is_dist():
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf
+
+
+def all_reduce_mean(payload: torch.Tensor, count: float) -> torch.Tensor:
+    """commu_utils.all_reduce(data, 'sum', average=True) with the count folded into the same buffer."""
+    buf = torch.cat((payload.reshape(-1).float(), torch.tensor([count], dtype=torch.float32, device=payload.device)))
+    if is_dist():
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return (buf[:-1] / buf[-1]).view_as(payload)

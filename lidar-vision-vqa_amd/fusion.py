@@ -108,7 +108,8 @@ class VATBlock(_HipModule):
     def project_kv(self, kv_bf: BF) -> BF:
         """K|V projection of the cross-attention: [B*Nkv, d] -> [B*Nkv, 2d] (rows d..3d of in_proj)."""
         d = self.d_model
-        _, kvp = ops.linear(kv_bf, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(d, 3 * d))
+        _, kvp = ops.linear(kv_bf, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(d, 3 * d),
+                            tag="ca_kv_proj")
         return kvp
 
     def _cross_attn(self, q2: torch.Tensor, kvp: BF, B: int, nq: int, nkv: int) -> torch.Tensor:
@@ -116,12 +117,12 @@ class VATBlock(_HipModule):
         dh = d // h
         split = self._split()
         _, qn = ops.layernorm(q2, self.ca_ln.weight, self.ca_ln.bias, self.ca_ln.eps, split)
-        _, qp = ops.linear(qn, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(0, d))
+        _, qp = ops.linear(qn, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(0, d), tag="ca_q_proj")
         vsl = (kvp[0][:, d:], None if kvp[1] is None else kvp[1][:, d:])
         o = ops.attention(qp, kvp, vsl, batch=B, n_heads=h, n_kv_heads=h, nq=nq, nkv=nkv, dh=dh,
                           q_strides=(nq * d, d, dh), k_strides=(nkv * 2 * d, 2 * d, dh), v_strides=(nkv * 2 * d, 2 * d, dh),
-                          scale=1.0 / math.sqrt(dh))
-        y, _ = ops.linear(o, self._w(self.ca.out_proj.weight), self.ca.out_proj.bias, residual=q2, out_f32=True)
+                          scale=1.0 / math.sqrt(dh), tag="ca_attn")
+        y, _ = ops.linear(o, self._w(self.ca.out_proj.weight), self.ca.out_proj.bias, residual=q2, out_f32=True, tag="ca_out_proj")
         return y
 
     def _mlp(self, q2: torch.Tensor) -> torch.Tensor:

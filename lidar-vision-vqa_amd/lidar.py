@@ -157,16 +157,21 @@ class MeanVFE(VFETemplate):
         return self.num_point_features
 
     @torch.no_grad()
-    def forward(self, batch_dict, **kwargs):
-        voxels = batch_dict["voxels"].contiguous()
-        num = _as_i32(batch_dict["voxel_num_points"]).contiguous()
+    def forward_device(self, voxels: torch.Tensor, num: torch.Tensor, n_live: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Sync-free form: rows >= n_live[0] (device int32) are skipped; returns [cap, c]."""
         F.require_cuda(voxels, num)
         m, t, c = voxels.shape
         out = torch.empty((m, c), dtype=torch.float32, device=voxels.device)
-        rc = F.lib().lvq_mean_vfe(F.ptr(voxels), F.ptr(num), F.i64(m), F.ptr(None), F.cint(t), F.cint(c), F.ptr(out),
+        rc = F.lib().lvq_mean_vfe(F.ptr(voxels), F.ptr(num), F.i64(m), F.ptr(n_live), F.cint(t), F.cint(c), F.ptr(out),
                                   F.stream_ptr(voxels.device))
         F.check(rc, "lvq_mean_vfe")
-        batch_dict["voxel_features"] = out
+        return out
+
+    @torch.no_grad()
+    def forward(self, batch_dict, **kwargs):
+        voxels = batch_dict["voxels"].contiguous()
+        num = _as_i32(batch_dict["voxel_num_points"]).contiguous()
+        batch_dict["voxel_features"] = self.forward_device(voxels, num)
         return batch_dict
 
 
@@ -237,22 +242,28 @@ class PillarVFE(_PFNStack):
         self._geom(voxel_size, point_cloud_range)
 
     @torch.no_grad()
-    def forward(self, batch_dict, **kwargs):
+    def forward_device(self, voxels, num, coords, n_live: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Sync-free form on capacity-sized buffers (int32 num / coords); rows >= n_live[0] are skipped."""
         self._inference_only()
-        voxels = batch_dict["voxels"].contiguous()
-        num = _as_i32(batch_dict["voxel_num_points"]).contiguous()
-        coords = _as_i32(batch_dict["voxel_coords"]).contiguous()
         F.require_cuda(voxels, num, coords)
         m, t, c = voxels.shape
         keep, wp, sp, hp, cin, cout, flags, c_last = self._abi_layers()
         out = torch.empty((m, c_last), dtype=torch.float32, device=voxels.device)
-        rc = F.lib().lvq_pillar_vfe(F.ptr(voxels), F.ptr(num), F.ptr(coords), F.i64(m), F.ptr(None), F.cint(t), F.cint(c),
+        rc = F.lib().lvq_pillar_vfe(F.ptr(voxels), F.ptr(num), F.ptr(coords), F.i64(m), F.ptr(n_live), F.cint(t), F.cint(c),
                                     F.cint(len(self.pfn_layers)), wp, sp, hp, cin, cout, F.cint(flags),
                                     F.f32x([self.voxel_x, self.voxel_y, self.voxel_z]),
                                     F.f32x([self.x_offset, self.y_offset, self.z_offset]), F.ptr(out),
                                     F.stream_ptr(voxels.device))
         F.check(rc, "lvq_pillar_vfe")
         del keep
+        return out
+
+    @torch.no_grad()
+    def forward(self, batch_dict, **kwargs):
+        voxels = batch_dict["voxels"].contiguous()
+        num = _as_i32(batch_dict["voxel_num_points"]).contiguous()
+        coords = _as_i32(batch_dict["voxel_coords"]).contiguous()
+        out = self.forward_device(voxels, num, coords)
         batch_dict["pillar_features"] = out.squeeze()   # pillar_vfe.py:121 `features.squeeze()`
         return batch_dict
 
@@ -410,20 +421,27 @@ class PointPillarScatter(nn.Module):
         assert self.nz == 1
 
     @torch.no_grad()
+    def forward_device(self, feats, coords, batch_size: int, n_live: Optional[torch.Tensor] = None,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Sync-free form: feats [cap,ch] fp32, coords [cap,4] int32 (b,z,y,x), rows >= n_live[0] skipped."""
+        F.require_cuda(feats, coords)
+        m, ch = feats.shape
+        assert ch == self.num_bev_features
+        canvas = out if out is not None else torch.empty((batch_size, ch * self.nz, self.ny, self.nx), dtype=torch.float32,
+                                                         device=feats.device)
+        rc = F.lib().lvq_pillar_scatter(F.ptr(feats), F.ptr(coords), F.i64(m), F.ptr(n_live), F.cint(ch), F.cint(batch_size),
+                                        F.cint(self.ny), F.cint(self.nx), F.ptr(canvas), F.stream_ptr(feats.device))
+        F.check(rc, "lvq_pillar_scatter")
+        return canvas
+
+    @torch.no_grad()
     def forward(self, batch_dict, **kwargs):
         feats = batch_dict["pillar_features"].contiguous()
         coords = _as_i32(batch_dict["voxel_coords"]).contiguous()
-        F.require_cuda(feats, coords)
         if feats.dim() == 1:
             feats = feats.view(1, -1)
-        m, ch = feats.shape
-        assert ch == self.num_bev_features
         batch_size = int(batch_dict["batch_size"]) if "batch_size" in batch_dict else int(coords[:, 0].max().item()) + 1
-        canvas = torch.empty((batch_size, ch * self.nz, self.ny, self.nx), dtype=torch.float32, device=feats.device)
-        rc = F.lib().lvq_pillar_scatter(F.ptr(feats), F.ptr(coords), F.i64(m), F.ptr(None), F.cint(ch), F.cint(batch_size),
-                                        F.cint(self.ny), F.cint(self.nx), F.ptr(canvas), F.stream_ptr(feats.device))
-        F.check(rc, "lvq_pillar_scatter")
-        batch_dict["spatial_features"] = canvas
+        batch_dict["spatial_features"] = self.forward_device(feats, coords, batch_size)
         return batch_dict
 
 

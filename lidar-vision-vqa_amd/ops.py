@@ -30,6 +30,33 @@ def set_default_precision(p: str):
     _default_precision = p
 
 
+# Optional per-launch timing with HIP events ON THE LAUNCH STREAM (bench.py's roofline leg): when EVENTS is a
+# dict, every tagged launch appends (start, end) torch.cuda.Event pairs under its tag.
+EVENTS = None
+
+
+class _Region:
+    def __init__(self, tag, device):
+        self.tag, self.device = tag, device
+
+    def __enter__(self):
+        if EVENTS is not None and self.tag:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record(torch.cuda.current_stream(self.device))
+        return self
+
+    def __exit__(self, *exc):
+        if EVENTS is not None and self.tag:
+            self.e.record(torch.cuda.current_stream(self.device))
+            EVENTS.setdefault(self.tag, []).append((self.s, self.e))
+        return False
+
+
+def region(tag, device):
+    return _Region(tag, device)
+
+
 def _bf_empty(shape, dev, split: bool) -> BF:
     hi = torch.empty(shape, dtype=torch.bfloat16, device=dev)
     return hi, (torch.empty(shape, dtype=torch.bfloat16, device=dev) if split else None)
@@ -78,7 +105,7 @@ def rmsnorm(x: torch.Tensor, gamma: torch.Tensor, eps: float, split: bool) -> BF
 
 def linear(a: BF, w: BF, bias: Optional[torch.Tensor] = None, *, gelu: bool = False, alpha: float = 1.0,
            residual: Optional[torch.Tensor] = None, rowtab: Optional[torch.Tensor] = None, out_f32: bool = False,
-           out_bf: bool = False, w_rows: Optional[Tuple[int, int]] = None):
+           out_bf: bool = False, w_rows: Optional[Tuple[int, int]] = None, tag: Optional[str] = None):
     """y = a @ w[r0:r1].T (+bias[r0:r1]) ... ; a hi [M,K], w hi [N,K].  Returns (y_f32 | None, BF | None)."""
     ah, al = a
     wh, wl = w
@@ -93,12 +120,13 @@ def linear(a: BF, w: BF, bias: Optional[torch.Tensor] = None, *, gelu: bool = Fa
     wo = r0 * k * 2  # byte offset of the weight row slice
     bo = r0 * 4
     import ctypes
-    rc = F.lib().lvq_gemm_bf16(
-        F.ptr(ah), F.ptr(al), ctypes.c_void_p(wh.data_ptr() + wo), ctypes.c_void_p(wl.data_ptr() + wo if split else 0),
-        ctypes.c_void_p(bias.data_ptr() + bo if bias is not None else 0), F.ptr(residual), F.ptr(rowtab),
-        F.i64(rowtab.shape[0] if rowtab is not None else 0), F.cfloat(alpha), F.cint(1 if gelu else 0), F.i64(m), F.cint(n),
-        F.cint(k), F.i64(k), F.i64(k), F.i64(n), F.cint(1), F.i64(0), F.i64(0), F.i64(0), F.ptr(c32), F.ptr(ch), F.ptr(cl),
-        F.stream_ptr(dev))
+    with region(tag, dev):
+        rc = F.lib().lvq_gemm_bf16(
+            F.ptr(ah), F.ptr(al), ctypes.c_void_p(wh.data_ptr() + wo), ctypes.c_void_p(wl.data_ptr() + wo if split else 0),
+            ctypes.c_void_p(bias.data_ptr() + bo if bias is not None else 0), F.ptr(residual), F.ptr(rowtab),
+            F.i64(rowtab.shape[0] if rowtab is not None else 0), F.cfloat(alpha), F.cint(1 if gelu else 0), F.i64(m), F.cint(n),
+            F.cint(k), F.i64(k), F.i64(k), F.i64(n), F.cint(1), F.i64(0), F.i64(0), F.i64(0), F.ptr(c32), F.ptr(ch), F.ptr(cl),
+            F.stream_ptr(dev))
     F.check(rc, f"lvq_gemm_bf16 (m={m}, n={n}, k={k})")
     return c32, ((ch, cl) if out_bf else None)
 
@@ -107,7 +135,8 @@ _ATT_WS = {}
 
 
 def attention(q: BF, k: BF, v: BF, *, batch: int, n_heads: int, n_kv_heads: int, nq: int, nkv: int, dh: int,
-              q_strides, k_strides, v_strides, scale: float, bias: Optional[torch.Tensor] = None, causal: bool = False) -> BF:
+              q_strides, k_strides, v_strides, scale: float, bias: Optional[torch.Tensor] = None, causal: bool = False,
+              tag: Optional[str] = None) -> BF:
     """q/k/v: BF views (possibly column slices of packed projections); *_strides = (batch, row, head) in elements.
     Returns BF [batch*nq, n_heads*dh]."""
     import ctypes
@@ -125,14 +154,15 @@ def attention(q: BF, k: BF, v: BF, *, batch: int, n_heads: int, n_kv_heads: int,
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
         _ATT_WS[key] = ws
     d = n_heads * dh
-    rc = L.lvq_attention_bf16(
-        F.ptr(qh), F.ptr(ql), F.ptr(k[0]), F.ptr(k[1]), F.ptr(v[0]), F.ptr(v[1]), F.ptr(bias), F.cint(batch), F.cint(n_heads),
-        F.cint(n_kv_heads), F.cint(nq), F.cint(nkv), F.cint(dh),
-        F.i64(q_strides[0]), F.i64(q_strides[1]), F.i64(q_strides[2]),
-        F.i64(k_strides[0]), F.i64(k_strides[1]), F.i64(k_strides[2]),
-        F.i64(v_strides[0]), F.i64(v_strides[1]), F.i64(v_strides[2]),
-        F.i64(nq * d), F.i64(d), F.i64(dh), F.cfloat(scale), F.cint(1 if causal else 0), F.ptr(oh), F.ptr(ol),
-        F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
+    with region(tag, dev):
+        rc = L.lvq_attention_bf16(
+            F.ptr(qh), F.ptr(ql), F.ptr(k[0]), F.ptr(k[1]), F.ptr(v[0]), F.ptr(v[1]), F.ptr(bias), F.cint(batch), F.cint(n_heads),
+            F.cint(n_kv_heads), F.cint(nq), F.cint(nkv), F.cint(dh),
+            F.i64(q_strides[0]), F.i64(q_strides[1]), F.i64(q_strides[2]),
+            F.i64(k_strides[0]), F.i64(k_strides[1]), F.i64(k_strides[2]),
+            F.i64(v_strides[0]), F.i64(v_strides[1]), F.i64(v_strides[2]),
+            F.i64(nq * d), F.i64(d), F.i64(dh), F.cfloat(scale), F.cint(1 if causal else 0), F.ptr(oh), F.ptr(ol),
+            F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
     F.check(rc, f"lvq_attention_bf16 (B={batch}, H={n_heads}, nq={nq}, nkv={nkv}, dh={dh})")
     return oh, ol
 
