@@ -186,3 +186,28 @@ def scale_add_rows(x: torch.Tensor, add: Optional[torch.Tensor], alpha: float = 
                                     F.i64(rows), F.cint(d), F.ptr(out), F.stream_ptr(x.device))
     F.check(rc, "lvq_scale_add_rows")
     return out
+
+
+def rope_inplace(x: BF, rows: int, seq_len: int, n_heads: int, dh: int, ld: int, theta: float):
+    """Rotary embedding applied in place to a (column slice of a) packed projection; position = row % seq_len."""
+    hi, lo = x
+    rc = F.lib().lvq_rope_inplace(F.ptr(hi), F.ptr(lo), F.i64(rows), F.cint(seq_len), F.cint(n_heads), F.cint(dh), F.i64(ld),
+                                  F.cfloat(theta), F.stream_ptr(hi.device))
+    F.check(rc, "lvq_rope_inplace")
+
+
+def swiglu(gate_up: torch.Tensor, split: bool) -> BF:
+    rows, two_i = gate_up.shape
+    hi, lo = _bf_empty((rows, two_i // 2), gate_up.device, split)
+    rc = F.lib().lvq_swiglu(F.ptr(gate_up), F.i64(rows), F.cint(two_i // 2), F.ptr(hi), F.ptr(lo), F.stream_ptr(gate_up.device))
+    F.check(rc, "lvq_swiglu")
+    return hi, lo
+
+
+def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """Mean CE over labels >= 0 (ignore_index -100): returns a 0-dim device tensor, no host sync."""
+    rows, vocab = logits.shape
+    acc = torch.zeros(2, dtype=torch.float32, device=logits.device)
+    rc = F.lib().lvq_cross_entropy(F.ptr(logits), F.ptr(labels), F.i64(rows), F.cint(vocab), F.ptr(acc), F.stream_ptr(logits.device))
+    F.check(rc, "lvq_cross_entropy")
+    return acc[0] / acc[1]
