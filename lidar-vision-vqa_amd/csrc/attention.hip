@@ -17,6 +17,8 @@
 // lvq_attention_bf16 (scores via lvq_gemm_bf16 + lvq_softmax_rows).  NSPLIT = 3 is the bf16x3 mode
 // (hi/lo operands, three MFMA passes) that meets the 1e-3 parity bar; NSPLIT = 1 is plain bf16.
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -32,157 +34,308 @@ struct AttnArgs {
     float scale;
     int causal;
     uint16_t *o, *ol;
+    int nsplit;       // KV splits (flash-decoding style) for few-queries x many-keys shapes
+    int nqt;          // query tiles (of 64*QT queries)
+    float *part;      // [B*H][nsplit][Nq][dh + 2] fp32 partial (unnormalised O | m | l) when nsplit > 1
 };
 
 constexpr int KVB = 64;  // keys per tile
 
-template <int DHP, int NSPLIT>
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+// two fp32 -> packed bf16 pair (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved)
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    bf16x2_t p = {(__bf16)a, (__bf16)b};
+    return *reinterpret_cast<uint32_t *>(&p);
+}
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// raw v_exp_f32 (no denormal fix-up sequence: arguments here are <= 0 and tiny results may flush to zero)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// max over the four lane groups g = lane>>4 that hold different keys of the same query (VALU permlane swaps, no LDS)
+__device__ __forceinline__ float max_over_groups(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+// QT = 16-query column tiles per wave: a wave owns 16*QT queries and reuses every K / V fragment QT times.
+// The main loop is written for a lean instruction stream (the first version issued ~1100 instructions per 18
+// MFMAs and was VALU-issue-bound): K/V tiles arrive through buffer loads whose per-lane offset is loop
+// invariant and whose tile offset is a scalar (hardware bounds check = zero fill past Nkv), exponentials are raw
+// v_exp_f32, the row maximum uses v_max3 chains + two permlane swaps, the row sum is an extra MFMA row, and
+// bias / causal / ragged-tile handling lives in a separate slow path taken only by the tiles that need it.
+template <int DHP, int NSPLIT, int QT>
 __global__ void __launch_bounds__(256) k_attn(AttnArgs a) {
     constexpr int NS = (NSPLIT == 3) ? 2 : 1;
-    constexpr int KROW = DHP + 8;       // bf16 elements per K row (+16 B pad: odd multiple of 16 B)
-    constexpr int VROW = KVB + 4;       // bf16 elements per V^T row
+    constexpr int KROW = DHP + 8;       // bf16 elements per K / V row (+16 B pad: odd multiple of 16 B)
     constexpr int NC = DHP / 32;        // 32-wide k chunks of the head dim
     constexpr int ND = DHP / 16;        // 16-wide output tiles of the head dim
+    constexpr int QW = 16 * QT;         // queries per wave
+    constexpr int CH = DHP / 8;                      // 16-byte chunks per row
+    constexpr int NLD = (KVB * CH + 255) / 256;      // chunks per thread per operand
+    constexpr int TILE_E = 2 * NS * KVB * KROW;      // bf16 elements of one K+V stage
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-    uint16_t *Ks = smem;                          // [NS][KVB][KROW]
-    uint16_t *Vt = smem + NS * KVB * KROW;        // [NS][DHP][VROW]
+    // per stage: Ks [NS][KVB][KROW] row-major keys | Vs [NS][KVB][KROW] row-major values (read transposed by
+    // ds_read_b64_tr_b16); two stages
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, l15 = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y, hk = h / (a.H / a.Hkv);
-    const int q0 = blockIdx.x * 64 + wid * 16;
-    const int qi = q0 + l15;
-    const float LOG2E = 1.4426950408889634f;
+    // 1-D grid, query tile fastest: the nqt workgroups that stream the same K/V range are adjacent in dispatch order
+    const int grp = blockIdx.x / a.nqt, qtile = blockIdx.x - grp * a.nqt;
+    const int sp = grp % a.nsplit, h = (grp / a.nsplit) % a.H, b = grp / (a.nsplit * a.H);
+    const int hk = h / (a.H / a.Hkv);
+    const int q0 = qtile * (4 * QW) + wid * QW;
+    const float cexp = a.scale * 1.4426950408889634f;   // scores are exponentiated in the log2 domain
 
-    // Q fragments (B operand of S^T = K Q^T): lane supplies Q[qi][c*32 + 8g .. +7]
-    bf16x8 qf[NS][NC];
+    // Q fragments (B operand of S^T = K Q^T): lane supplies Q[q0 + qt*16 + l15][c*32 + 8g .. +7]
+    bf16x8 qf[NS][QT][NC];
     {
         const uint16_t *src[2] = {a.q, a.ql};
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int kk = c * 32 + g * 8;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (qi < a.Nq && kk < a.dh)
-                    v = *reinterpret_cast<const uint4 *>(src[s] + (int64_t)b * a.q_bs + (int64_t)qi * a.ldq + (int64_t)h * a.q_hs + kk);
-                qf[s][c] = *reinterpret_cast<bf16x8 *>(&v);
-            }
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const int kk = c * 32 + g * 8, qi = q0 + qt * 16 + l15;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (qi < a.Nq && kk < a.dh)
+                        v = *reinterpret_cast<const uint4 *>(src[s] + (int64_t)b * a.q_bs + (int64_t)qi * a.ldq + (int64_t)h * a.q_hs + kk);
+                    qf[s][qt][c] = *reinterpret_cast<bf16x8 *>(&v);
+                }
     }
 
-    f32x4 o[ND];
+    // o[ND] is the row-sum tile: V^T is extended by a row of ones, so l = sum_j p_j falls out of the same MFMAs
+    f32x4 o[ND + 1][QT];
 #pragma unroll
-    for (int n = 0; n < ND; ++n) o[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int n = 0; n <= ND; ++n)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[n][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) m_run[qt] = -INFINITY;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (short)0x3F80;
 
     const int n_tiles = (a.Nkv + KVB - 1) / KVB;
-    const uint16_t *ksrc[2] = {a.k, a.kl}, *vsrc[2] = {a.v, a.vl};
-    for (int t = 0; t < n_tiles; ++t) {
-        // ---- stage K (row-major) and V (transposed) into LDS ----
-        constexpr int CH = DHP / 8;  // 16-byte chunks per row
-        for (int e = tid; e < KVB * CH; e += 256) {
-            const int r = e / CH, ch = e - r * CH, kk = ch * 8;
-            const int key = t * KVB + r;
-            const bool ok = key < a.Nkv && kk < a.dh;
+    const int tps = (n_tiles + a.nsplit - 1) / a.nsplit;
+    const int t0 = sp * tps;
+    int t1 = t0 + tps < n_tiles ? t0 + tps : n_tiles;
+    if (a.causal) {   // keys beyond the last visible one of this workgroup's last query are never needed
+        int qlast = qtile * (4 * QW) + 4 * QW - 1;
+        if (qlast > a.Nq - 1) qlast = a.Nq - 1;
+        const int tl = (qlast + a.Nkv - a.Nq) / KVB + 1;
+        if (t1 > tl) t1 = tl;
+    }
+
+    // ---- K/V staging: buffer descriptors cover exactly the valid rows of this (batch, kv-head), so rows past Nkv
+    // read as zero in hardware; the per-lane byte offset is loop invariant, the tile offset is a scalar ----
+    const int wave_b = __builtin_amdgcn_readfirstlane(b), wave_hk = __builtin_amdgcn_readfirstlane(hk);
+    __amdgpu_buffer_rsrc_t rk[NS], rv[NS];
+    {
+        const uint16_t *kb[2] = {a.k, a.kl}, *vb[2] = {a.v, a.vl};
+        const uint32_t kbytes = (uint32_t)(((int64_t)(a.Nkv - 1) * a.ldk + a.dh) * 2);
+        const uint32_t vbytes = (uint32_t)(((int64_t)(a.Nkv - 1) * a.ldv + a.dh) * 2);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            rk[s] = __builtin_amdgcn_make_buffer_rsrc((void *)(kb[s] + (int64_t)wave_b * a.k_bs + (int64_t)wave_hk * a.k_hs), 0, kbytes, 0x00020000);
+            rv[s] = __builtin_amdgcn_make_buffer_rsrc((void *)(vb[s] + (int64_t)wave_b * a.v_bs + (int64_t)wave_hk * a.v_hs), 0, vbytes, 0x00020000);
+        }
+    }
+    uint32_t koff[NLD], voff[NLD], lso[NLD];
+    bool live[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int e = tid + 256 * i, r = e / CH, kk = (e - r * CH) * 8;
+        live[i] = (e < KVB * CH) && (kk < a.dh);        // head-dim padding chunks stay zero
+        koff[i] = (uint32_t)((r * a.ldk + kk) * 2);
+        voff[i] = (uint32_t)((r * a.ldv + kk) * 2);
+        lso[i] = (uint32_t)(r * KROW + kk);
+    }
+    const uint32_t ktile = (uint32_t)(KVB * a.ldk * 2), vtile = (uint32_t)(KVB * a.ldv * 2);
+    i32x4 sk[NS][NLD], sv[NS][NLD];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                uint4 kv4 = make_uint4(0, 0, 0, 0), vv4 = make_uint4(0, 0, 0, 0);
-                if (ok) {
-                    kv4 = *reinterpret_cast<const uint4 *>(ksrc[s] + (int64_t)b * a.k_bs + (int64_t)key * a.ldk + (int64_t)hk * a.k_hs + kk);
-                    vv4 = *reinterpret_cast<const uint4 *>(vsrc[s] + (int64_t)b * a.v_bs + (int64_t)key * a.ldv + (int64_t)hk * a.v_hs + kk);
+                sk[s][i] = i32x4{0, 0, 0, 0};
+                sv[s][i] = i32x4{0, 0, 0, 0};
+                if (live[i]) {
+                    sk[s][i] = __builtin_amdgcn_raw_buffer_load_b128(rk[s], koff[i], t * ktile, 0);
+                    sv[s][i] = __builtin_amdgcn_raw_buffer_load_b128(rv[s], voff[i], t * vtile, 0);
                 }
-                *reinterpret_cast<uint4 *>(Ks + (s * KVB + r) * KROW + kk) = kv4;
-                const uint16_t *ve = reinterpret_cast<const uint16_t *>(&vv4);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) Vt[(s * DHP + kk + i) * VROW + r] = ve[i];
             }
-        }
-        __syncthreads();
+    };
+    auto lstore = [&](int buf) {
+        uint16_t *kd = smem + buf * TILE_E, *vd = kd + NS * KVB * KROW;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (tid + 256 * i < KVB * CH) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    *reinterpret_cast<i32x4 *>(kd + s * KVB * KROW + lso[i]) = sk[s][i];
+                    *reinterpret_cast<i32x4 *>(vd + s * KVB * KROW + lso[i]) = sv[s][i];
+                }
+            }
+    };
 
-        // ---- S^T tiles: rows = keys kt*16 + g*4 + r, column = query l15 ----
-        f32x4 sc[4];
+    // ---- one 64-key tile.  MASKED = false: every key is valid and visible, no bias (the common case) ----
+    auto tile = [&](const uint16_t *Ks, const uint16_t *Vs, int t, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const int kleft = a.Nkv - t * KVB;
+        const int nkt = (!MASKED || kleft >= KVB) ? 4 : (kleft + 15) >> 4;   // 16-key sub-tiles holding a valid key
+        f32x4 sc[4][QT];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
-            sc[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const bf16x8 kh = *reinterpret_cast<const bf16x8 *>(Ks + (kt * 16 + l15) * KROW + c * 32 + g * 8);
-                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qf[0][c], sc[kt], 0, 0, 0);
-                if (NSPLIT == 3) {
-                    const bf16x8 kl = *reinterpret_cast<const bf16x8 *>(Ks + (KVB + kt * 16 + l15) * KROW + c * 32 + g * 8);
-                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qf[NS - 1][c], sc[kt], 0, 0, 0);
-                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qf[0][c], sc[kt], 0, 0, 0);
+            for (int qt = 0; qt < QT; ++qt) sc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!MASKED || kt < nkt) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const bf16x8 kh = *reinterpret_cast<const bf16x8 *>(Ks + (kt * 16 + l15) * KROW + c * 32 + g * 8);
+                    bf16x8 kl;
+                    if (NSPLIT == 3) kl = *reinterpret_cast<const bf16x8 *>(Ks + (KVB + kt * 16 + l15) * KROW + c * 32 + g * 8);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        sc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qf[0][qt][c], sc[kt][qt], 0, 0, 0);
+                        if (NSPLIT == 3) {
+                            sc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qf[NS - 1][qt][c], sc[kt][qt], 0, 0, 0);
+                            sc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl, qf[0][qt][c], sc[kt][qt], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
-        // ---- scale, bias, masks; online softmax in the log2 domain ----
-        float tmax = -INFINITY;
+        uint32_t pk[QT][4][2], pkl[QT][4][2];   // packed bf16 P^T [qt][kt][pair], hi and (bf16x3) lo parts
+        bool any_grow = false;
+        float alpha[QT];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int qt = 0; qt < QT; ++qt) {
+            if (MASKED) {
+                const int qi = q0 + qt * 16 + l15;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = t * KVB + kt * 16 + g * 4 + r;
-                float x = sc[kt][r] * a.scale;
-                if (a.bias && key < a.Nkv && qi < a.Nq)
-                    x += a.bias[(((int64_t)b * a.H + h) * a.Nq + qi) * a.Nkv + key];
-                x *= LOG2E;
-                if (key >= a.Nkv || (a.causal && key > qi + a.Nkv - a.Nq)) x = -INFINITY;
-                sc[kt][r] = x;
-                tmax = fmaxf(tmax, x);
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = t * KVB + kt * 16 + g * 4 + r;
+                        if (a.bias && key < a.Nkv && qi < a.Nq)   // folded so that one fma(x, cexp, -m) serves both terms
+                            sc[kt][qt][r] += a.bias[(((int64_t)b * a.H + h) * a.Nq + qi) * a.Nkv + key] / a.scale;
+                        if (key >= a.Nkv || (a.causal && key > qi + a.Nkv - a.Nq)) sc[kt][qt][r] = -INFINITY;
+                    }
             }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-        const float m_new = fmaxf(m_run, tmax);
-        const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_safe);
-        float rs = 0.f;
+            float tmax = fmaxf(fmaxf(sc[0][qt][0], sc[0][qt][1]), fmaxf(sc[0][qt][2], sc[0][qt][3]));
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 1; kt < 4; ++kt)
+                tmax = fmaxf(fmaxf(fmaxf(tmax, sc[kt][qt][0]), fmaxf(sc[kt][qt][1], sc[kt][qt][2])), sc[kt][qt][3]);
+            tmax = max_over_groups(tmax);
+            const float m_new = fmaxf(m_run[qt], tmax * cexp);
+            const float m_safe = (MASKED && m_new == -INFINITY) ? 0.f : m_new;
+            alpha[qt] = fast_exp2(m_run[qt] - m_safe);
+            any_grow = any_grow || (m_new != m_run[qt]);
+            m_run[qt] = m_new;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = exp2f(sc[kt][r] - m_safe);
-                sc[kt][r] = p;
-                rs += p;
+            for (int kt = 0; kt < 4; ++kt) {
+                float p[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] = fast_exp2(fmaf(sc[kt][qt][r], cexp, -m_safe));
+                pk[qt][kt][0] = pack_bf16(p[0], p[1]);
+                pk[qt][kt][1] = pack_bf16(p[2], p[3]);
+                if (NSPLIT == 3) {
+                    pkl[qt][kt][0] = pack_bf16(p[0] - __uint_as_float(pk[qt][kt][0] << 16), p[1] - __uint_as_float(pk[qt][kt][0] & 0xffff0000u));
+                    pkl[qt][kt][1] = pack_bf16(p[2] - __uint_as_float(pk[qt][kt][1] << 16), p[3] - __uint_as_float(pk[qt][kt][1] & 0xffff0000u));
+                }
             }
-        rs += __shfl_xor(rs, 16);
-        rs += __shfl_xor(rs, 32);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
+        }
+        // rescale the accumulators only when some running max moved (exact: alpha == 1 otherwise)
+        if (__any(any_grow)) {
 #pragma unroll
-        for (int n = 0; n < ND; ++n) o[n] *= alpha;
-
-        // ---- O^T += V^T P^T : A = V^T[d][keys], B = P^T[keys][query] straight from the score registers ----
+            for (int n = 0; n <= ND; ++n)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) o[n][qt] *= alpha[qt];
+        }
+        // O^T += V^T P^T : A = V^T[d][keys] via the transposing LDS read, B = P^T straight from the registers.
+        // k index of step s2, element j of lane group g  <->  key (2*s2 + (j>>2))*16 + 4g + (j&3)   (both operands)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 ph, pl;
+            if (!MASKED || 2 * s2 < nkt) {
+                bf16x8 pf[QT], pfl[QT];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float p = (j < 4) ? sc[2 * s2][j] : sc[2 * s2 + 1][j - 4];
-                const uint16_t hh = f32_to_bf16(p);
-                ph[j] = (short)hh;
-                if (NSPLIT == 3) pl[j] = (short)f32_to_bf16(p - bf16_to_f32(hh));
-            }
+                for (int qt = 0; qt < QT; ++qt) {
+                    uint4 u = make_uint4(pk[qt][2 * s2][0], pk[qt][2 * s2][1], pk[qt][2 * s2 + 1][0], pk[qt][2 * s2 + 1][1]);
+                    pf[qt] = *reinterpret_cast<bf16x8 *>(&u);
+                    if (NSPLIT == 3) {
+                        uint4 ul = make_uint4(pkl[qt][2 * s2][0], pkl[qt][2 * s2][1], pkl[qt][2 * s2 + 1][0], pkl[qt][2 * s2 + 1][1]);
+                        pfl[qt] = *reinterpret_cast<bf16x8 *>(&ul);
+                    }
+                }
+                // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of its group's 4-key x 16-d block
+                const uint16_t *vbase = Vs + ((2 * s2) * 16 + 4 * g + (l15 >> 2)) * KROW + 4 * (l15 & 3);
 #pragma unroll
-            for (int n = 0; n < ND; ++n) {
-                const uint16_t *vrow = Vt + (n * 16 + l15) * VROW + g * 4;
-                bf16x4 v0 = *reinterpret_cast<const bf16x4 *>(vrow + (2 * s2) * 16);
-                bf16x4 v1 = *reinterpret_cast<const bf16x4 *>(vrow + (2 * s2 + 1) * 16);
-                bf16x8 vh = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, ph, o[n], 0, 0, 0);
-                if (NSPLIT == 3) {
-                    const uint16_t *vrl = vrow + DHP * VROW;
-                    bf16x4 w0 = *reinterpret_cast<const bf16x4 *>(vrl + (2 * s2) * 16);
-                    bf16x4 w1 = *reinterpret_cast<const bf16x4 *>(vrl + (2 * s2 + 1) * 16);
-                    bf16x8 vlo = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pl, o[n], 0, 0, 0);
-                    o[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vlo, ph, o[n], 0, 0, 0);
+                for (int n = 0; n < ND; ++n) {
+                    const uint16_t *va = vbase + n * 16;
+                    bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)va);
+                    bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)(va + 16 * KROW));
+                    const bf16x8 vh = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    bf16x8 vlo;
+                    if (NSPLIT == 3) {
+                        bf16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)(va + KVB * KROW));
+                        bf16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)(va + (KVB + 16) * KROW));
+                        vlo = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        o[n][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pf[qt], o[n][qt], 0, 0, 0);
+                        if (NSPLIT == 3) {
+                            o[n][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pfl[qt], o[n][qt], 0, 0, 0);
+                            o[n][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vlo, pf[qt], o[n][qt], 0, 0, 0);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {     // row sums: the ones-row of V^T
+                    o[ND][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qt], o[ND][qt], 0, 0, 0);
+                    if (NSPLIT == 3) o[ND][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pfl[qt], o[ND][qt], 0, 0, 0);
                 }
             }
         }
+    };
+
+    // K/V tiles are double-buffered in LDS: the loads of tile t+1 are issued before the MFMAs of tile t and written
+    // to the other buffer after them (issue-early / write-late), one barrier per tile.
+    if (t0 < t1) { gload(t0); lstore(0); }
+    __syncthreads();
+    const bool special = a.bias != nullptr || a.causal;
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        const uint16_t *Ks = smem + buf * TILE_E, *Vs = Ks + NS * KVB * KROW;
+        if (t + 1 < t1) gload(t + 1);
+        if (special || (t + 1) * KVB > a.Nkv) tile(Ks, Vs, t, std::true_type{});
+        else tile(Ks, Vs, t, std::false_type{});
+        if (t + 1 < t1) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // ---- normalise and store: lane holds O[qi][n*16 + g*4 + r] ----
-    if (qi < a.Nq) {
+    // ---- write back: lane holds O[q0 + qt*16 + l15][n*16 + g*4 + r]; o[ND][qt][*] = l ----
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int qi = q0 + qt * 16 + l15;
+        if (qi >= a.Nq) continue;
+        const float l_run = o[ND][qt][0];
+        if (a.nsplit > 1) {
+            float *pr = a.part + ((((int64_t)b * a.H + h) * a.nsplit + sp) * a.Nq + qi) * (a.dh + 2);
+#pragma unroll
+            for (int n = 0; n < ND; ++n) {
+                const int d0 = n * 16 + g * 4;
+                if (d0 < a.dh) *reinterpret_cast<f32x4 *>(pr + d0) = o[n][qt];
+            }
+            if (g == 0) { pr[a.dh] = m_run[qt]; pr[a.dh + 1] = l_run; }
+            continue;
+        }
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
         uint16_t *dst = a.o + (int64_t)b * a.o_bs + (int64_t)qi * a.ldo + (int64_t)h * a.o_hs;
         uint16_t *dl = a.ol ? a.ol + (int64_t)b * a.o_bs + (int64_t)qi * a.ldo + (int64_t)h * a.o_hs : nullptr;
@@ -190,28 +343,103 @@ __global__ void __launch_bounds__(256) k_attn(AttnArgs a) {
         for (int n = 0; n < ND; ++n) {
             const int d0 = n * 16 + g * 4;
             if (d0 >= a.dh) continue;
-            ushort4 hv, lv;
-            uint16_t *hp = reinterpret_cast<uint16_t *>(&hv), *lp = reinterpret_cast<uint16_t *>(&lv);
+            float y[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float y = o[n][r] * inv;
-                hp[r] = f32_to_bf16(y);
-                lp[r] = f32_to_bf16(y - bf16_to_f32(hp[r]));
+            for (int r = 0; r < 4; ++r) y[r] = o[n][qt][r] * inv;
+            uint2 hv = make_uint2(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]));
+            *reinterpret_cast<uint2 *>(dst + d0) = hv;
+            if (dl) {
+                uint2 lv = make_uint2(pack_bf16(y[0] - __uint_as_float(hv.x << 16), y[1] - __uint_as_float(hv.x & 0xffff0000u)),
+                                      pack_bf16(y[2] - __uint_as_float(hv.y << 16), y[3] - __uint_as_float(hv.y & 0xffff0000u)));
+                *reinterpret_cast<uint2 *>(dl + d0) = lv;
             }
-            *reinterpret_cast<ushort4 *>(dst + d0) = hv;
-            if (dl) *reinterpret_cast<ushort4 *>(dl + d0) = lv;
         }
     }
 }
 
-template <int DHP, int NSPLIT> int launch_attn(const AttnArgs &a, hipStream_t st) {
+// merge the KV splits: out = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s
+__global__ void __launch_bounds__(256) k_attn_combine(AttnArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int dq = a.dh / 4;
+    const int64_t total = (int64_t)a.B * a.H * a.Nq * dq;
+    if (idx >= total) return;
+    const int d0 = (int)(idx % dq) * 4;
+    const int64_t row = idx / dq;                    // (b*H + h)*Nq + qi
+    const int qi = (int)(row % a.Nq);
+    const int64_t bh = row / a.Nq;
+    const int h = (int)(bh % a.H), b = (int)(bh / a.H);
+    const int stride = a.dh + 2;
+    float M = -INFINITY;
+    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, a.part[((bh * a.nsplit + s) * a.Nq + qi) * stride + a.dh]);
+    const float Ms = (M == -INFINITY) ? 0.f : M;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, l = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) {
+        const float *pr = a.part + ((bh * a.nsplit + s) * a.Nq + qi) * stride;
+        const float w = exp2f(pr[a.dh] - Ms);
+        l += w * pr[a.dh + 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += w * pr[d0 + r];
+    }
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = acc[r] * inv;
+    const int64_t off = (int64_t)b * a.o_bs + (int64_t)qi * a.ldo + (int64_t)h * a.o_hs + d0;
+    uint2 hv = make_uint2(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]));
+    *reinterpret_cast<uint2 *>(a.o + off) = hv;
+    if (a.ol) {
+        uint2 lv = make_uint2(pack_bf16(y[0] - __uint_as_float(hv.x << 16), y[1] - __uint_as_float(hv.x & 0xffff0000u)),
+                              pack_bf16(y[2] - __uint_as_float(hv.y << 16), y[3] - __uint_as_float(hv.y & 0xffff0000u)));
+        *reinterpret_cast<uint2 *>(a.ol + off) = lv;
+    }
+}
+
+// launch geometry shared by lvq_attention_workspace_bytes and lvq_attention_bf16
+struct AttnPlan { int qt, nqt, nsplit; };
+AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split) {
+    AttnPlan p;
+    const int dhp = (dh + 31) / 32 * 32;
+    int qmax = (dhp <= 64 && !split) ? 4 : 2;
+    if (dhp > 64 && split) qmax = 1;
+    // Measured on MI355X (tools/bench_kernels.py attn, LVQ_ATTN_QT sweep): one 16-query tile per wave (4 waves/SIMD
+    // resident) beats 2 or 4 tiles per wave on every shape tried -- occupancy hides the softmax VALU and the
+    // staging latency better than K/V fragment reuse saves LDS reads.
+    p.qt = 1;
+    if (const char *ev = getenv("LVQ_ATTN_QT")) {      // tuning knob (tools/bench_kernels.py); not used in production
+        const int f = atoi(ev);
+        if ((f == 1 || f == 2 || f == 4) && f <= qmax) p.qt = f;
+    }
+    p.nqt = (nq + 64 * p.qt - 1) / (64 * p.qt);
+    const int64_t base = (int64_t)p.nqt * n_heads * batch;
+    const int n_tiles = (nkv + KVB - 1) / KVB;
+    int ns = (int)((512 + base - 1) / base);
+    if (ns > n_tiles / 8) ns = n_tiles / 8;            // at least 8 KV tiles per split
+    if (ns < 1) ns = 1;
+    if (ns > 64) ns = 64;
+    p.nsplit = ns;
+    return p;
+}
+
+template <int DHP, int NSPLIT, int QT> int launch_attn_qt(AttnArgs &a, hipStream_t st) {
     constexpr int NS = (NSPLIT == 3) ? 2 : 1;
-    const size_t lds = (size_t)(NS * KVB * (DHP + 8) + NS * DHP * (KVB + 4)) * sizeof(uint16_t);
+    const size_t lds = (size_t)(2 * 2 * NS * KVB * (DHP + 8)) * sizeof(uint16_t);   // two K+V stages
     if (lds > 64 * 1024)
-        hipFuncSetAttribute((const void *)k_attn<DHP, NSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid((unsigned)lvq_cdiv(a.Nq, 64), (unsigned)a.H, (unsigned)a.B);
-    hipLaunchKernelGGL((k_attn<DHP, NSPLIT>), grid, dim3(256), lds, st, a);
+        hipFuncSetAttribute((const void *)k_attn<DHP, NSPLIT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t nwg = (int64_t)a.B * a.H * a.nsplit * a.nqt;
+    if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
+    dim3 grid((unsigned)nwg);
+    hipLaunchKernelGGL((k_attn<DHP, NSPLIT, QT>), grid, dim3(256), lds, st, a);
+    if (a.nsplit > 1) {
+        const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
+        hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
+    }
     return lvq_launch_status();
+}
+
+template <int DHP, int NSPLIT> int launch_attn(AttnArgs &a, int qt, hipStream_t st) {
+    if (DHP <= 64 && NSPLIT == 1 && qt == 4) return launch_attn_qt<DHP, NSPLIT, (DHP <= 64 && NSPLIT == 1) ? 4 : 1>(a, st);
+    if (!(DHP > 64 && NSPLIT == 3) && qt >= 2) return launch_attn_qt<DHP, NSPLIT, (DHP > 64 && NSPLIT == 3) ? 1 : 2>(a, st);
+    return launch_attn_qt<DHP, NSPLIT, 1>(a, st);
 }
 
 // row softmax for the split (large head-dim) path: p = softmax(s*scale + bias, causal) -> bf16 hi/lo
@@ -265,7 +493,11 @@ __global__ void __launch_bounds__(256) k_transpose_bf16(const uint16_t *__restri
 }  // namespace
 
 extern "C" size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, int nkv, int dh, int precision) {
-    if (dh <= 128) return 256;
+    if (dh <= 128 && (dh & 15) == 0) {              // fused kernel: workspace only for the KV-split partials
+        AttnPlan p = plan_attn(batch, n_heads, nq, nkv, dh, precision == 3);
+        if (p.nsplit == 1) return 256;
+        return lvq_align((size_t)batch * n_heads * p.nsplit * nq * (dh + 2) * sizeof(float)) + 256;
+    }
     const int64_t nkp = (nkv + 7) / 8 * 8;
     const int ns = precision == 3 ? 2 : 1;
     size_t s = (size_t)n_heads * nq * nkv * sizeof(float);            // scores of one batch element
@@ -294,6 +526,8 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
         return LVQ_EUNSUPPORTED;
     if (((uintptr_t)o | (uintptr_t)o_lo) & 7) return LVQ_EUNSUPPORTED;
     if (n_heads > 65535 || batch > 65535) return LVQ_EUNSUPPORTED;
+    // the fused kernel addresses one (batch, kv-head) K / V slab with 32-bit buffer offsets
+    if (((int64_t)nkv * ldk + dh) * 2 >= (1ll << 32) || ((int64_t)nkv * ldv + dh) * 2 >= (1ll << 32)) return LVQ_EUNSUPPORTED;
     hipStream_t st = lvq_s(stream);
     if (dh <= 128 && (dh & 15) == 0) {
         AttnArgs a;
@@ -303,19 +537,26 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
         a.v_bs = v_bstride; a.ldv = ldv; a.v_hs = v_hstride; a.o_bs = o_bstride; a.ldo = ldo; a.o_hs = o_hstride;
         a.scale = scale; a.causal = causal; a.o = o; a.ol = o_lo;
         const int dhp = (dh + 31) / 32 * 32;
+        const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, split);
+        a.nsplit = pl.nsplit; a.nqt = pl.nqt; a.part = nullptr;
+        if (pl.nsplit > 1) {
+            LvqArena arena(ws, ws_bytes);
+            a.part = arena.take<float>((size_t)batch * n_heads * pl.nsplit * nq * (dh + 2));
+            if (!arena.ok) return LVQ_EWORKSPACE;
+        }
         if (!split) {
             switch (dhp) {
-                case 32: return launch_attn<32, 1>(a, st);
-                case 64: return launch_attn<64, 1>(a, st);
-                case 96: return launch_attn<96, 1>(a, st);
-                default: return launch_attn<128, 1>(a, st);
+                case 32: return launch_attn<32, 1>(a, pl.qt, st);
+                case 64: return launch_attn<64, 1>(a, pl.qt, st);
+                case 96: return launch_attn<96, 1>(a, pl.qt, st);
+                default: return launch_attn<128, 1>(a, pl.qt, st);
             }
         } else {
             switch (dhp) {
-                case 32: return launch_attn<32, 3>(a, st);
-                case 64: return launch_attn<64, 3>(a, st);
-                case 96: return launch_attn<96, 3>(a, st);
-                default: return launch_attn<128, 3>(a, st);
+                case 32: return launch_attn<32, 3>(a, pl.qt, st);
+                case 64: return launch_attn<64, 3>(a, pl.qt, st);
+                case 96: return launch_attn<96, 3>(a, pl.qt, st);
+                default: return launch_attn<128, 3>(a, pl.qt, st);
             }
         }
     }

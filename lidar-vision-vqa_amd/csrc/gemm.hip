@@ -40,9 +40,23 @@ struct GemmArgs {
     int64_t a_bs, w_bs, c_bs;
     float *c32;
     uint16_t *c16, *c16lo;
+    int ntx;            // tiles along N
+    int vec_epilogue;   // every C-side pointer / stride is 8-element aligned -> LDS-transposed 16-byte stores
 };
 
-template <int BM, int BN>
+// XCD-aware tile order: workgroups b and b+8 share an XCD (and its L2).  Give each XCD a CONTIGUOUS range of
+// tiles (x fastest) so the N/BN tiles that re-read one A row-panel run on one L2 (cdna_hip_programming T1,
+// bijective form for any tile count).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// GLDS = 1: K % 64 == 0 fast path, tiles staged with global_load_lds_dwordx4 (LDS-DMA: no VGPRs, no ds_write
+// pass).  The DMA writes lane-linear 1-KiB pieces (8 rows x 128 B), so the bank swizzle is applied to the
+// per-lane SOURCE address and again on the ds_read (both-sides rule).  GLDS = 0: register staging with
+// per-chunk predication for ragged K.
+template <int BM, int BN, int GLDS>
 __global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
     constexpr int BK = 64;
     constexpr int TM = BM / 32, TN = BN / 32;      // MFMA tiles per wave
@@ -52,8 +66,9 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int64_t m0 = (int64_t)blockIdx.y * BM;
-    const int n0 = blockIdx.x * BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(tile / g.ntx) * BM;
+    const int n0 = (tile % g.ntx) * BN;
     const int64_t z = blockIdx.z;
     const int nk = (g.K + BK - 1) / BK;
     const int n_it = nk * g.nseg;
@@ -96,12 +111,44 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
+    auto stage_dma = [&](int it, int buf) {
+        const int seg = it / nk, k0 = (it - seg * nk) * BK;
+        const uint16_t *A = g.a[seg] + z * g.a_bs;
+        const uint16_t *W = g.w[seg] + z * g.w_bs;
+        uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
+        const int r8 = lane >> 3, pch = lane & 7;
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) {
+            const int piece = i * 4 + wid, row = piece * 8 + r8;
+            int64_t gm = m0 + row;
+            gm = gm < g.M ? gm : g.M - 1;                    // clamped rows are never stored
+            const uint16_t *src = A + gm * g.lda + k0 + ((pch ^ ((row >> 1) & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(sa + piece * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const int piece = i * 4 + wid, row = piece * 8 + r8;
+            int gn = n0 + row;
+            gn = gn < g.N ? gn : g.N - 1;
+            const uint16_t *src = W + (int64_t)gn * g.ldw + k0 + ((pch ^ ((row >> 1) & 7)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(sb + piece * 1024), 16, 0, 0);
+        }
+    };
+
+    if (GLDS) {
+        stage_dma(0, 0);
+    } else {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();   // with an LDS-DMA in flight hipcc emits s_waitcnt vmcnt(0) in front of this barrier
     for (int it = 0; it < n_it; ++it) {
         const int buf = it & 1;
-        if (it + 1 < n_it) gload(it + 1);
+        if (it + 1 < n_it) {
+            if (GLDS) stage_dma(it + 1, buf ^ 1); else gload(it + 1);
+        }
         const uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -124,12 +171,82 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (it + 1 < n_it) lstore(buf ^ 1);
+        if (!GLDS && it + 1 < n_it) lstore(buf ^ 1);
         __syncthreads();
     }
 
-    // epilogue: C/D layout of 16x16x32: lane l holds rows (l>>4)*4 + r, column l & 15
+    // ---- epilogue ----
+    // C/D layout of 16x16x32: lane l holds rows (l>>4)*4 + r, column l & 15 of each 16x16 tile.
     const bool gelu = g.flags & LVQ_GEMM_GELU;
+    if (g.vec_epilogue) {
+        // Transpose through a wave-private LDS slab so that every lane owns 8 CONSECUTIVE columns of one row:
+        // bias / residual / table reads and all stores become 16- or 32-byte accesses (the direct layout
+        // gives 2-byte bf16 stores in 32-byte row segments, which made K <= 768 GEMMs store-bound).
+        constexpr int HR = (BM / 2) / 2;                 // rows per half of the wave tile (32 or 16)
+        constexpr int WC = BN / 2;                       // columns of the wave tile (64 or 32)
+        constexpr int LDE = WC + 4;                      // padded row (floats); (WC+4)*4 B is a multiple of 16
+        constexpr int CPR = WC / 8;                      // 8-column chunks per row
+        float *ep = reinterpret_cast<float *>(smem) + wid * (HR * LDE);
+        static_assert(4 * HR * LDE * 4 <= 2 * STAGE, "epilogue slab must fit in the staging LDS");
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int ii = 0; ii < TM / 2; ++ii)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ep[(ii * 16 + (lane >> 4) * 4 + r) * LDE + j * 16 + (lane & 15)] = acc[hh * (TM / 2) + ii][j][r];
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int p = 0; p < (HR * CPR) / 64; ++p) {
+                const int q = p * 64 + lane, rr = q / CPR, c8 = q % CPR;
+                const int64_t row = m0 + wm * (BM / 2) + hh * HR + rr;
+                const int col = n0 + wn * WC + c8 * 8;
+                float v[8];
+                *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8);
+                *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8 + 4);
+                if (row < g.M && col < g.N) {     // N % 8 == 0 in this path: a chunk is all-in or all-out
+                    if (g.bias) {
+                        const float4 b0 = *reinterpret_cast<const float4 *>(g.bias + col), b1 = *reinterpret_cast<const float4 *>(g.bias + col + 4);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
+                    if (gelu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
+                    const int64_t o = z * g.c_bs + row * g.ldc + col;
+                    if (g.residual) {
+                        const float4 r0 = *reinterpret_cast<const float4 *>(g.residual + o), r1 = *reinterpret_cast<const float4 *>(g.residual + o + 4);
+                        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                    }
+                    if (g.rowtab) {
+                        const float *t = g.rowtab + (row % g.rowtab_rows) * g.N + col;
+                        const float4 t0 = *reinterpret_cast<const float4 *>(t), t1 = *reinterpret_cast<const float4 *>(t + 4);
+                        v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+                    }
+                    if (g.c32) {
+                        *reinterpret_cast<float4 *>(g.c32 + o) = *reinterpret_cast<float4 *>(v);
+                        *reinterpret_cast<float4 *>(g.c32 + o + 4) = *reinterpret_cast<float4 *>(v + 4);
+                    }
+                    if (g.c16) {
+                        uint16_t hb[8], lb[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { hb[e] = f32_to_bf16(v[e]); lb[e] = f32_to_bf16(v[e] - bf16_to_f32(hb[e])); }
+                        *reinterpret_cast<uint4 *>(g.c16 + o) = *reinterpret_cast<uint4 *>(hb);
+                        if (g.c16lo) *reinterpret_cast<uint4 *>(g.c16lo + o) = *reinterpret_cast<uint4 *>(lb);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    // scalar fallback (N, ldc or a pointer not 8-element aligned)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -211,16 +328,24 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
     g.alpha = alpha; g.flags = flags; g.M = m; g.N = n; g.K = k;
     g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.a_bs = a_bs; g.w_bs = w_bs; g.c_bs = c_bs;
     g.c32 = c_f32; g.c16 = c_bf16; g.c16lo = c_lo;
+    g.vec_epilogue = (n % 8 == 0) && (ldc % 8 == 0) && (c_bs % 8 == 0) &&
+                     !(((uintptr_t)c_f32 | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)rowtab) & 15) &&
+                     !(((uintptr_t)c_bf16 | (uintptr_t)c_lo) & 15);
     hipStream_t st = lvq_s(stream);
     const int64_t big_tiles = lvq_cdiv(m, 128) * lvq_cdiv(n, 128) * batch;
-    if (big_tiles >= 192) {
-        dim3 grid((unsigned)lvq_cdiv(n, 128), (unsigned)lvq_cdiv(m, 128), (unsigned)batch);
-        if (grid.y > 65535) return LVQ_EUNSUPPORTED;
-        hipLaunchKernelGGL((k_gemm_bf16<128, 128>), grid, dim3(256), 2 * (128 + 128) * 128, st, g);
+    const bool dma = (k % 64) == 0;      // LDS-DMA path needs whole 64-wide K tiles (no per-chunk zero fill)
+    const int bm = big_tiles >= 192 ? 128 : 64;
+    const int64_t tiles = lvq_cdiv(n, bm) * lvq_cdiv(m, bm);
+    if (tiles > 0x7fffffff || batch > 65535) return LVQ_EUNSUPPORTED;
+    g.ntx = (int)lvq_cdiv(n, bm);
+    dim3 grid((unsigned)tiles, 1, (unsigned)batch);
+    const size_t lds = (size_t)2 * (bm + bm) * 128;
+    if (bm == 128) {
+        if (dma) hipLaunchKernelGGL((k_gemm_bf16<128, 128, 1>), grid, dim3(256), lds, st, g);
+        else     hipLaunchKernelGGL((k_gemm_bf16<128, 128, 0>), grid, dim3(256), lds, st, g);
     } else {
-        dim3 grid((unsigned)lvq_cdiv(n, 64), (unsigned)lvq_cdiv(m, 64), (unsigned)batch);
-        if (grid.y > 65535) return LVQ_EUNSUPPORTED;
-        hipLaunchKernelGGL((k_gemm_bf16<64, 64>), grid, dim3(256), 2 * (64 + 64) * 128, st, g);
+        if (dma) hipLaunchKernelGGL((k_gemm_bf16<64, 64, 1>), grid, dim3(256), lds, st, g);
+        else     hipLaunchKernelGGL((k_gemm_bf16<64, 64, 0>), grid, dim3(256), lds, st, g);
     }
     return lvq_launch_status();
 }

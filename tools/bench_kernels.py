@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on the MI355X (HIP events, random data, interleaved rounds in ONE process --
+cdna_hip_programming.md rules 24/25).  Usage on the GPU box:
+
+    python tools/bench_kernels.py gemm attn norm vox
+"""
+from __future__ import annotations
+
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from lidar_vision_vqa_amd import lidar, ops, synth  # noqa: E402
+
+DEV = torch.device("cuda:0")
+torch.set_grad_enabled(False)
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for _ in range(3):
+        s.record()
+        for _ in range(iters):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e) / iters)
+    return min(ts), float(np.median(ts))
+
+
+def bench_gemm():
+    shapes = [(4 * 262144, 1536, 768, "VATLiDAR K|V proj (S=4)"), (262144, 1536, 768, "K|V proj (S=1)"),
+              (32768, 768, 768, "headline Q / out proj"), (4 * 262144, 768, 64, "1x1 conv proj (S=4)"),
+              (8192, 8192, 8192, "square 8k"), (4096, 4096, 4096, "square 4k"), (2304, 3072, 768, "MLP up (S=4,nq=576)"),
+              (2304, 768, 3072, "MLP down"), (784, 1536, 768, "patch K|V (S=4)")]
+    print(f"{'shape':>28} {'what':>28} {'mode':>7} {'ms(min)':>9} {'TFLOP/s':>9} {'frac':>6}")
+    for m, n, k, what in shapes:
+        a = torch.randn(m, k, device=DEV)
+        w = torch.randn(n, k, device=DEV) * 0.05
+        bias = torch.randn(n, device=DEV)
+        for split in (False, True):
+            ab, wb = ops.cast(a, split), ops.cast(w, split)
+            t, _ = timeit(lambda: ops.linear(ab, wb, bias, out_bf=True), iters=10)
+            fl = 2.0 * m * n * k
+            print(f"{str((m, n, k)):>28} {what:>28} {'x3' if split else 'bf16':>7} {t:9.4f} {fl / t / 1e9:9.1f} {fl / t / 1e9 / 2500:6.3f}")
+        del a, w
+
+
+def bench_attn():
+    cases = [(4, 12, 576, 262144, 64, "VATLiDAR ca (S=4)"), (1, 12, 32768, 196, 64, "headline 32k x 196"),
+             (4, 12, 576, 196, 64, "fusion ca"), (4, 12, 576, 576, 64, "self-attn"), (16, 16, 2048, 2048, 128, "flash ref shape")]
+    print(f"{'B,H,Nq,Nkv,dh':>28} {'what':>22} {'mode':>6} {'ms':>9} {'TFLOP/s':>9}")
+    for B, H, nq, nkv, dh, what in cases:
+        d = H * dh
+        q = torch.randn(B * nq, d, device=DEV)
+        kv = torch.randn(B * nkv, 2 * d, device=DEV)
+        for split in (False, True):
+            qb, kvb = ops.cast(q, split), ops.cast(kv, split)
+            vsl = (kvb[0][:, d:], None if kvb[1] is None else kvb[1][:, d:])
+            fn = lambda: ops.attention(qb, kvb, vsl, batch=B, n_heads=H, n_kv_heads=H, nq=nq, nkv=nkv, dh=dh,
+                                       q_strides=(nq * d, d, dh), k_strides=(nkv * 2 * d, 2 * d, dh),
+                                       v_strides=(nkv * 2 * d, 2 * d, dh), scale=1 / math.sqrt(dh))
+            t, _ = timeit(fn, iters=5)
+            fl = 4.0 * B * nq * nkv * d
+            print(f"{str((B, H, nq, nkv, dh)):>28} {what:>22} {'x3' if split else 'bf16':>6} {t:9.4f} {fl / t / 1e9:9.1f}")
+        del q, kv
+
+
+def bench_norm():
+    for rows, d in [(4 * 262144, 768), (2304, 768)]:
+        x = torch.randn(rows, d, device=DEV)
+        g, b = torch.randn(d, device=DEV), torch.randn(d, device=DEV)
+        post = torch.randn(262144, d, device=DEV) if rows > 262144 else None
+        t, _ = timeit(lambda: ops.layernorm(x, g, b, 1e-5, False, post=post), iters=5)
+        by = rows * d * (4 + 2) + (rows * d * 4 if post is not None else 0)
+        print(f"layernorm rows={rows} d={d}: {t:.4f} ms  {by / t / 1e6:.0f} GB/s algorithmic")
+
+
+def bench_vox():
+    rng = list(synth.PC_RANGE_NUSC)
+    for S, n, vs, T, mv, what in [(8, 65536, synth.VOXEL_01, 10, 160000, "cfg-3 0.1m"), (1, 32768, synth.VOXEL_01, 10, 60000, "cfg-2 0.1m"),
+                                  (64, 32768, synth.VOXEL_01, 10, 60000, "64 scenes 0.1m"), (8, 65536, synth.VOXEL_PILLAR, 20, 30000, "pillars")]:
+        scenes = [synth.scene_points("C", n, 1010 + i) for i in range(min(S, 8))]
+        scenes = (scenes * ((S + 7) // 8))[:S]
+        pts = torch.from_numpy(np.concatenate(scenes)).to(DEV)
+        off = torch.tensor(np.concatenate(([0], np.cumsum([len(s) for s in scenes]))), dtype=torch.int32, device=DEV)
+        gen = lidar.VoxelGeneratorWrapper(vs, rng, 4, T, mv)
+        out = gen.generate_batch_device(pts, off, S)
+        M = int(out[3][-1])
+        t, _ = timeit(lambda: gen.generate_batch_device(pts, off, S), iters=10)
+        by = 16 * pts.shape[0] + M * (4 * T * 4 + 20)
+        print(f"hard voxelise {what}: S={S} N={pts.shape[0]} M={M}: {t * 1e3:.1f} us  {by / t / 1e6:.0f} GB/s algorithmic ({by / t / 1e6 / 8000:.3f} of 8 TB/s)")
+        mvfe = lidar.MeanVFE(None, 4)
+        t2, _ = timeit(lambda: mvfe.forward_device(out[0], out[2], out[3][S:]), iters=10)
+        print(f"   MeanVFE: {t2 * 1e3:.1f} us  {(M * (4 * T * 4 + 4 + 16)) / t2 / 1e6:.0f} GB/s")
+        bp = torch.cat((torch.repeat_interleave(torch.arange(S, device=DEV, dtype=torch.float32), torch.tensor([len(s) for s in scenes], device=DEV)).unsqueeze(1), pts), 1).contiguous()
+        grid = lidar.grid_size_from(rng, vs)
+        ndim = 3 if grid[2] > 1 else 2
+        t3, _ = timeit(lambda: lidar._dynamic_voxelize(bp, S, rng, vs, grid, ndim), iters=10)
+        print(f"   dynamic voxelise: {t3 * 1e3:.1f} us  {(20 * bp.shape[0] + M * 16) / t3 / 1e6:.0f} GB/s algorithmic")
+
+
+def bench_attn_one():
+    """One shape, few launches: the target of `rocprofv3 --pmc`."""
+    B, H, nq, nkv, dh = (int(v) for v in os.environ.get("ATTN_SHAPE", "4,12,576,262144,64").split(","))
+    d = H * dh
+    q = torch.randn(B * nq, d, device=DEV)
+    kv = torch.randn(B * nkv, 2 * d, device=DEV)
+    qb, kvb = ops.cast(q, False), ops.cast(kv, False)
+    vsl = (kvb[0][:, d:], None)
+    fn = lambda: ops.attention(qb, kvb, vsl, batch=B, n_heads=H, n_kv_heads=H, nq=nq, nkv=nkv, dh=dh, q_strides=(nq * d, d, dh),
+                               k_strides=(nkv * 2 * d, 2 * d, dh), v_strides=(nkv * 2 * d, 2 * d, dh), scale=1 / math.sqrt(dh))
+    t, _ = timeit(fn, iters=3, warm=1)
+    print(f"attn {B,H,nq,nkv,dh}: {t:.4f} ms {4.0 * B * nq * nkv * d / t / 1e9:.1f} TFLOP/s")
+
+
+def bench_gemm_one():
+    m, n, k = (int(v) for v in os.environ.get("GEMM_SHAPE", "1048576,1536,768").split(","))
+    a = torch.randn(m, k, device=DEV)
+    w = torch.randn(n, k, device=DEV) * 0.05
+    ab, wb = ops.cast(a, False), ops.cast(w, False)
+    t, _ = timeit(lambda: ops.linear(ab, wb, None, out_bf=True), iters=3, warm=1)
+    print(f"gemm {m,n,k}: {t:.4f} ms {2.0 * m * n * k / t / 1e9:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemm", "attn", "norm", "vox"]
+    for w in which:
+        print(f"==== {w} ====")
+        {"gemm": bench_gemm, "attn": bench_attn, "norm": bench_norm, "vox": bench_vox, "attn1": bench_attn_one,
+         "gemm1": bench_gemm_one}[w]()
