@@ -404,7 +404,7 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split) 
     // Measured on MI355X (tools/bench_kernels.py attn, LVQ_ATTN_QT sweep): one 16-query tile per wave (4 waves/SIMD
     // resident) beats 2 or 4 tiles per wave on every shape tried -- occupancy hides the softmax VALU and the
     // staging latency better than K/V fragment reuse saves LDS reads.
-    p.qt = 1;
+    p.qt = (dhp >= 96 && !split) ? 2 : 1;             // head_dim 96/128: two tiles per wave measured faster (377 vs 267 TFLOP/s)
     if (const char *ev = getenv("LVQ_ATTN_QT")) {      // tuning knob (tools/bench_kernels.py); not used in production
         const int f = atoi(ev);
         if ((f == 1 || f == 2 || f == 4) && f <= qmax) p.qt = f;

@@ -64,6 +64,67 @@ __global__ void __launch_bounds__(256) k_norm(const float *__restrict__ x, const
     }
 }
 
+// d % 256 == 0 and d <= 2048: the row lives in registers (NV float4 per lane), one pass over HBM, 16-byte accesses
+template <bool RMS, int NV>
+__global__ void __launch_bounds__(256) k_norm_vec(const float *__restrict__ x, const float *__restrict__ add, int add_rows,
+                                                  int add_group, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                  float eps, int64_t rows, int d, const float *__restrict__ post,
+                                                  int64_t post_rows, float *__restrict__ y32,
+                                                  uint16_t *__restrict__ y16, uint16_t *__restrict__ ylo) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + row * d);
+    const float4 *ar = add ? reinterpret_cast<const float4 *>(add + ((row / add_group) % add_rows) * (int64_t)d) : nullptr;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = xr[i * 64 + lane];
+        if (ar) { const float4 t = ar[i * 64 + lane]; v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w; }
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = RMS ? 0.f : wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+    const float4 *pr = post ? reinterpret_cast<const float4 *>(post + (row % post_rows) * (int64_t)d) : nullptr;
+    const float4 *g4 = reinterpret_cast<const float4 *>(gamma), *b4 = reinterpret_cast<const float4 *>(beta);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 64 + lane;
+        const float4 gg = g4[c];
+        float4 y = make_float4(v[i].x * rstd * gg.x, v[i].y * rstd * gg.y, v[i].z * rstd * gg.z, v[i].w * rstd * gg.w);
+        if (!RMS && beta) { const float4 bb = b4[c]; y.x += bb.x; y.y += bb.y; y.z += bb.z; y.w += bb.w; }
+        if (pr) { const float4 pp = pr[c]; y.x += pp.x; y.y += pp.y; y.z += pp.z; y.w += pp.w; }
+        const int64_t o = row * d + c * 4;
+        if (y32) *reinterpret_cast<float4 *>(y32 + o) = y;
+        if (y16) {
+            const ushort4 hh = make_ushort4(f32_to_bf16(y.x), f32_to_bf16(y.y), f32_to_bf16(y.z), f32_to_bf16(y.w));
+            *reinterpret_cast<ushort4 *>(y16 + o) = hh;
+            if (ylo) *reinterpret_cast<ushort4 *>(ylo + o) = make_ushort4(f32_to_bf16(y.x - bf16_to_f32(hh.x)), f32_to_bf16(y.y - bf16_to_f32(hh.y)),
+                                                                         f32_to_bf16(y.z - bf16_to_f32(hh.z)), f32_to_bf16(y.w - bf16_to_f32(hh.w)));
+        }
+    }
+}
+
+template <bool RMS>
+bool launch_norm_vec(const float *x, const float *add, int add_rows, int add_group, const float *gamma, const float *beta, float eps,
+                     int64_t rows, int d, const float *post, int64_t post_rows, float *y32, uint16_t *y16, uint16_t *ylo, hipStream_t st) {
+    if (d % 256 || d > 2048) return false;
+    if (((uintptr_t)x | (uintptr_t)add | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)post | (uintptr_t)y32) & 15) return false;
+    if (((uintptr_t)y16 | (uintptr_t)ylo) & 7) return false;
+    dim3 grid((unsigned)lvq_cdiv(rows, 4)), block(256);
+#define LVQ_NV(N) case N: hipLaunchKernelGGL((k_norm_vec<RMS, N>), grid, block, 0, st, x, add, add_rows, add_group, gamma, beta, eps, rows, d, post, post_rows, y32, y16, ylo); return true;
+    switch (d / 256) { LVQ_NV(1) LVQ_NV(2) LVQ_NV(3) LVQ_NV(4) LVQ_NV(5) LVQ_NV(6) LVQ_NV(7) LVQ_NV(8) }
+#undef LVQ_NV
+    return false;
+}
+
 // depthwise 3x3 (pad 1) + GELU: block = 32 channels x one image row segment of 64 pixels
 __global__ void __launch_bounds__(256) k_dwconv3x3_gelu(const float *__restrict__ bev, const float *__restrict__ w9,
                                                         const float *__restrict__ bias, int C, int H, int W,
@@ -187,6 +248,9 @@ extern "C" int lvq_layernorm(const float *x, const float *add, int add_rows, int
     if (post_add && post_rows <= 0) return LVQ_EINVAL;
     if (rows == 0) return LVQ_OK;
     if (!x) return LVQ_EINVAL;
+    if (launch_norm_vec<false>(x, add, add_rows, add_group < 1 ? 1 : add_group, gamma, beta, eps, rows, d, post_add,
+                               post_rows < 1 ? 1 : post_rows, y_f32, y_bf16, y_lo, lvq_s(stream)))
+        return lvq_launch_status();
     hipLaunchKernelGGL(k_norm<false>, dim3((unsigned)lvq_cdiv(rows, 4)), dim3(256), 0, lvq_s(stream), x, add, add_rows,
                        add_group < 1 ? 1 : add_group, gamma, beta, eps, rows, d, post_add, post_rows < 1 ? 1 : post_rows, y_f32,
                        y_bf16, y_lo);
@@ -198,6 +262,8 @@ extern "C" int lvq_rmsnorm(const float *x, const float *gamma, float eps, int64_
     if (rows < 0 || d <= 0 || !gamma || (!y_f32 && !y_bf16) || (y_lo && !y_bf16)) return LVQ_EINVAL;
     if (rows == 0) return LVQ_OK;
     if (!x) return LVQ_EINVAL;
+    if (launch_norm_vec<true>(x, nullptr, 1, 1, gamma, nullptr, eps, rows, d, nullptr, 1, y_f32, y_bf16, y_lo, lvq_s(stream)))
+        return lvq_launch_status();
     hipLaunchKernelGGL(k_norm<true>, dim3((unsigned)lvq_cdiv(rows, 4)), dim3(256), 0, lvq_s(stream), x, (const float *)nullptr,
                        1, 1, gamma, (const float *)nullptr, eps, rows, d, (const float *)nullptr, (int64_t)1, y_f32, y_bf16, y_lo);
     return lvq_launch_status();

@@ -20,6 +20,7 @@
 // tiles, ~2^-17 relative operand error.  It is implemented as K-segments of one loop, so both modes
 // share every line of the kernel.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -56,16 +57,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // pass).  The DMA writes lane-linear 1-KiB pieces (8 rows x 128 B), so the bank swizzle is applied to the
 // per-lane SOURCE address and again on the ds_read (both-sides rule).  GLDS = 0: register staging with
 // per-chunk predication for ragged K.
-template <int BM, int BN, int GLDS>
-__global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
+// NW = 4: waves 2x2, two LDS stages, one vmcnt(0)+barrier per K tile (2 workgroups per CU hide the DMA latency).
+// NW = 8 (BM=256, BN=128, GLDS only): waves 4x2, THREE stages, tile t+2 is issued before tile t is consumed and the
+// wait is a COUNTED vmcnt that leaves it in flight across a raw s_barrier -- ~96 KB of loads in flight per CU,
+// which is what the short-K (K = 768) projections need to cover HBM latency.
+template <int BM, int BN, int GLDS, int GELU, int NW>
+__global__ void __launch_bounds__(NW * 64) k_gemm_bf16(GemmArgs g) {
     constexpr int BK = 64;
-    constexpr int TM = BM / 32, TN = BN / 32;      // MFMA tiles per wave
-    constexpr int LA = BM / 32, LB = BN / 32;      // 16-byte chunks per thread per stage
+    constexpr int WROWS = NW / 2;                  // wave grid WROWS x 2
+    constexpr int NT = NW * 64;
+    constexpr int NSTAGE = NW == 8 ? 3 : 2;
+    constexpr int TM = BM / (WROWS * 16), TN = BN / 32;      // MFMA tiles per wave
+    constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;        // 16-byte chunks per thread per stage
     constexpr int STAGE = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
+    constexpr int WTM = BM / WROWS;                // rows of the wave tile
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(tile / g.ntx) * BM;
     const int n0 = (tile % g.ntx) * BN;
@@ -80,13 +89,13 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
         const uint16_t *W = g.w[seg] + z * g.w_bs;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            const int q = tid + 256 * i, row = q >> 3, kk = k0 + (q & 7) * 8;
+            const int q = tid + NT * i, row = q >> 3, kk = k0 + (q & 7) * 8;
             const int64_t gm = m0 + row;
             ra[i] = (gm < g.M && kk < g.K) ? *reinterpret_cast<const uint4 *>(A + gm * g.lda + kk) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            const int q = tid + 256 * i, row = q >> 3, kk = k0 + (q & 7) * 8;
+            const int q = tid + NT * i, row = q >> 3, kk = k0 + (q & 7) * 8;
             const int gn = n0 + row;
             rb[i] = (gn < g.N && kk < g.K) ? *reinterpret_cast<const uint4 *>(W + (int64_t)gn * g.ldw + kk) : make_uint4(0, 0, 0, 0);
         }
@@ -95,12 +104,12 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
         uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
-            const int q = tid + 256 * i, row = q >> 3, ch = (q & 7) ^ ((row >> 1) & 7);
+            const int q = tid + NT * i, row = q >> 3, ch = (q & 7) ^ ((row >> 1) & 7);
             *reinterpret_cast<uint4 *>(sa + row * 128 + ch * 16) = ra[i];
         }
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            const int q = tid + 256 * i, row = q >> 3, ch = (q & 7) ^ ((row >> 1) & 7);
+            const int q = tid + NT * i, row = q >> 3, ch = (q & 7) ^ ((row >> 1) & 7);
             *reinterpret_cast<uint4 *>(sb + row * 128 + ch * 16) = rb[i];
         }
     };
@@ -118,8 +127,8 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
         uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
         const int r8 = lane >> 3, pch = lane & 7;
 #pragma unroll
-        for (int i = 0; i < BM / 32; ++i) {
-            const int piece = i * 4 + wid, row = piece * 8 + r8;
+        for (int i = 0; i < BM / (8 * NW); ++i) {
+            const int piece = i * NW + wid, row = piece * 8 + r8;
             int64_t gm = m0 + row;
             gm = gm < g.M ? gm : g.M - 1;                    // clamped rows are never stored
             const uint16_t *src = A + gm * g.lda + k0 + ((pch ^ ((row >> 1) & 7)) << 3);
@@ -127,8 +136,8 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
                                              (__attribute__((address_space(3))) void *)(sa + piece * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) {
-            const int piece = i * 4 + wid, row = piece * 8 + r8;
+        for (int i = 0; i < BN / (8 * NW); ++i) {
+            const int piece = i * NW + wid, row = piece * 8 + r8;
             int gn = n0 + row;
             gn = gn < g.N ? gn : g.N - 1;
             const uint16_t *src = W + (int64_t)gn * g.ldw + k0 + ((pch ^ ((row >> 1) & 7)) << 3);
@@ -137,25 +146,14 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
         }
     };
 
-    if (GLDS) {
-        stage_dma(0, 0);
-    } else {
-        gload(0);
-        lstore(0);
-    }
-    __syncthreads();   // with an LDS-DMA in flight hipcc emits s_waitcnt vmcnt(0) in front of this barrier
-    for (int it = 0; it < n_it; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < n_it) {
-            if (GLDS) stage_dma(it + 1, buf ^ 1); else gload(it + 1);
-        }
+    auto compute = [&](int buf) {
         const uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int row = wm * (BM / 2) + i * 16 + (lane & 15);
+                const int row = wm * WTM + i * 16 + (lane & 15);
                 const int ch = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
                 af[i] = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + ch * 16);
             }
@@ -171,23 +169,60 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (!GLDS && it + 1 < n_it) lstore(buf ^ 1);
-        __syncthreads();
+    };
+
+    if (NSTAGE == 3) {
+        // pieces per wave per stage: BM/(8*NW) + BN/(8*NW) global_load_lds instructions
+        stage_dma(0, 0);
+        if (n_it > 1) {
+            stage_dma(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / (8 * NW) + BN / (8 * NW)) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        int buf = 0;
+        for (int it = 0; it < n_it; ++it) {
+            int nb = buf + 2; nb = nb >= 3 ? nb - 3 : nb;
+            if (it + 2 < n_it) stage_dma(it + 2, nb);          // its buffer was last read in iteration it-1 (barrier since)
+            compute(buf);
+            if (it + 2 < n_it) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / (8 * NW) + BN / (8 * NW)) : "memory");   // tile it+1 landed, it+2 in flight
+            else               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            buf = buf + 1 >= 3 ? 0 : buf + 1;
+        }
+    } else {
+        if (GLDS) {
+            stage_dma(0, 0);
+        } else {
+            gload(0);
+            lstore(0);
+        }
+        __syncthreads();   // with an LDS-DMA in flight hipcc emits s_waitcnt vmcnt(0) in front of this barrier
+        for (int it = 0; it < n_it; ++it) {
+            const int buf = it & 1;
+            if (it + 1 < n_it) {
+                if (GLDS) stage_dma(it + 1, buf ^ 1); else gload(it + 1);
+            }
+            compute(buf);
+            if (!GLDS && it + 1 < n_it) lstore(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue ----
     // C/D layout of 16x16x32: lane l holds rows (l>>4)*4 + r, column l & 15 of each 16x16 tile.
-    const bool gelu = g.flags & LVQ_GEMM_GELU;
+    constexpr bool gelu = GELU != 0;     // template parameter: the inlined erff() is only instantiated where it is used
     if (g.vec_epilogue) {
         // Transpose through a wave-private LDS slab so that every lane owns 8 CONSECUTIVE columns of one row:
         // bias / residual / table reads and all stores become 16- or 32-byte accesses (the direct layout
         // gives 2-byte bf16 stores in 32-byte row segments, which made K <= 768 GEMMs store-bound).
-        constexpr int HR = (BM / 2) / 2;                 // rows per half of the wave tile (32 or 16)
+        constexpr int HR = WTM / 2;                      // rows per half of the wave tile (32 or 16)
         constexpr int WC = BN / 2;                       // columns of the wave tile (64 or 32)
         constexpr int LDE = WC + 4;                      // padded row (floats); (WC+4)*4 B is a multiple of 16
         constexpr int CPR = WC / 8;                      // 8-column chunks per row
         float *ep = reinterpret_cast<float *>(smem) + wid * (HR * LDE);
-        static_assert(4 * HR * LDE * 4 <= 2 * STAGE, "epilogue slab must fit in the staging LDS");
+        static_assert(NW * HR * LDE * 4 <= NSTAGE * STAGE, "epilogue slab must fit in the staging LDS");
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -199,10 +234,10 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
                         ep[(ii * 16 + (lane >> 4) * 4 + r) * LDE + j * 16 + (lane & 15)] = acc[hh * (TM / 2) + ii][j][r];
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int p = 0; p < (HR * CPR) / 64; ++p) {
+#pragma unroll 1
+            for (int p = 0; p < (HR * CPR) / 64; ++p) {     // rolled: the epilogue was 27k instructions (I-cache) fully unrolled
                 const int q = p * 64 + lane, rr = q / CPR, c8 = q % CPR;
-                const int64_t row = m0 + wm * (BM / 2) + hh * HR + rr;
+                const int64_t row = m0 + wm * WTM + hh * HR + rr;
                 const int col = n0 + wn * WC + c8 * 8;
                 float v[8];
                 *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8);
@@ -256,7 +291,7 @@ __global__ void __launch_bounds__(256) k_gemm_bf16(GemmArgs g) {
             const float bias = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t row = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + r;
+                const int64_t row = m0 + wm * WTM + i * 16 + (lane >> 4) * 4 + r;
                 if (row >= g.M) continue;
                 float v = acc[i][j][r] + bias;
                 if (gelu) v = gelu_erf(v);
@@ -334,19 +369,41 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
     hipStream_t st = lvq_s(stream);
     const int64_t big_tiles = lvq_cdiv(m, 128) * lvq_cdiv(n, 128) * batch;
     const bool dma = (k % 64) == 0;      // LDS-DMA path needs whole 64-wide K tiles (no per-chunk zero fill)
+    const bool ge = (flags & LVQ_GEMM_GELU) != 0;
+    // 256x128 / 8 waves / 3 stages when there is enough work to fill the chip with the bigger tile
+    const bool huge = dma && lvq_cdiv(m, 256) * lvq_cdiv(n, 128) * batch >= 512 && getenv("LVQ_GEMM_NO256") == nullptr;
+    if (batch > 65535) return LVQ_EUNSUPPORTED;
+    if (huge) {
+        const int64_t tiles = lvq_cdiv(n, 128) * lvq_cdiv(m, 256);
+        if (tiles > 0x7fffffff) return LVQ_EUNSUPPORTED;
+        g.ntx = (int)lvq_cdiv(n, 128);
+        dim3 grid((unsigned)tiles, 1, (unsigned)batch);
+        const size_t lds = (size_t)3 * (256 + 128) * 128;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipFuncSetAttribute((const void *)k_gemm_bf16<256, 128, 1, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute((const void *)k_gemm_bf16<256, 128, 1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        if (ge) hipLaunchKernelGGL((k_gemm_bf16<256, 128, 1, 1, 8>), grid, dim3(512), lds, st, g);
+        else    hipLaunchKernelGGL((k_gemm_bf16<256, 128, 1, 0, 8>), grid, dim3(512), lds, st, g);
+        return lvq_launch_status();
+    }
     const int bm = big_tiles >= 192 ? 128 : 64;
     const int64_t tiles = lvq_cdiv(n, bm) * lvq_cdiv(m, bm);
-    if (tiles > 0x7fffffff || batch > 65535) return LVQ_EUNSUPPORTED;
+    if (tiles > 0x7fffffff) return LVQ_EUNSUPPORTED;
     g.ntx = (int)lvq_cdiv(n, bm);
     dim3 grid((unsigned)tiles, 1, (unsigned)batch);
     const size_t lds = (size_t)2 * (bm + bm) * 128;
+#define LVQ_LAUNCH(BM_, DMA_, GE_) hipLaunchKernelGGL((k_gemm_bf16<BM_, BM_, DMA_, GE_, 4>), grid, dim3(256), lds, st, g)
     if (bm == 128) {
-        if (dma) hipLaunchKernelGGL((k_gemm_bf16<128, 128, 1>), grid, dim3(256), lds, st, g);
-        else     hipLaunchKernelGGL((k_gemm_bf16<128, 128, 0>), grid, dim3(256), lds, st, g);
+        if (dma) { if (ge) LVQ_LAUNCH(128, 1, 1); else LVQ_LAUNCH(128, 1, 0); }
+        else     { if (ge) LVQ_LAUNCH(128, 0, 1); else LVQ_LAUNCH(128, 0, 0); }
     } else {
-        if (dma) hipLaunchKernelGGL((k_gemm_bf16<64, 64, 1>), grid, dim3(256), lds, st, g);
-        else     hipLaunchKernelGGL((k_gemm_bf16<64, 64, 0>), grid, dim3(256), lds, st, g);
+        if (dma) { if (ge) LVQ_LAUNCH(64, 1, 1); else LVQ_LAUNCH(64, 1, 0); }
+        else     { if (ge) LVQ_LAUNCH(64, 0, 1); else LVQ_LAUNCH(64, 0, 0); }
     }
+#undef LVQ_LAUNCH
     return lvq_launch_status();
 }
 
