@@ -412,7 +412,9 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split) 
     p.nqt = (nq + 64 * p.qt - 1) / (64 * p.qt);
     const int64_t base = (int64_t)p.nqt * n_heads * batch;
     const int n_tiles = (nkv + KVB - 1) / KVB;
-    int ns = (int)((512 + base - 1) / base);
+    // enough workgroups for >= ~5 dispatch rounds (3 resident workgroups per CU): with ~1.1 rounds the straggler round
+    // doubled the kernel time (4 ms vs 8 ms run to run)
+    int ns = (int)((4096 + base - 1) / base);
     if (ns > n_tiles / 8) ns = n_tiles / 8;            // at least 8 KV tiles per split
     if (ns < 1) ns = 1;
     if (ns > 64) ns = 64;
