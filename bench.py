@@ -109,12 +109,22 @@ def main():
     big = [p for i, p in enumerate(kv_pairs) if (i % per_step) < cfg.n_layers]
     kv_ms = avg_ms(big)
     kv_flops = 2.0 * (S * h * w) * (2 * d) * d           # = 4*Nkv*d^2 per scene, x S scenes per launch
+    # HBM traffic of that launch from the PMC counters (FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 --pmc passes of the
+    # same kernel at the same shape, profiles/r01_pmc_traffic.json); counters cannot be read from inside this process
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            for k, v in json.load(f).items():
+                if k.startswith("k_gemm_bf16<256,128>") and S == 4 and (h, w, d) == (512, 512, 768):
+                    traffic = v["traffic_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = None
     if kv_ms:
         ach = kv_flops / (kv_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "k_gemm_bf16<256,128,LDS-DMA,3-stage> (VATLiDAR.ca K|V projection, M=S*HW, N=2d, K=d)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "traffic": None, "avg_launch_ms": round(kv_ms, 4), "flops_per_launch": kv_flops}
+                    "traffic": traffic, "avg_launch_ms": round(kv_ms, 4), "flops_per_launch": kv_flops}
 
     result = {
         "metric": "fused tokens/sec/GPU + cross-attn MFMA-roofline % (32k pts x 196 patches)",
