@@ -175,6 +175,14 @@ int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, co
                   int batch, int64_t a_bs, int64_t w_bs, int64_t c_bs, float *c_f32, lvq_bf16 *c_bf16,
                   lvq_bf16 *c_lo, lvq_stream_t stream);
 
+/* Row-complete Linear + LayerNorm (+ positional table) for the VATLiDAR token path (vat_lidar.py:222-248):
+ *   Y = LayerNorm(A W^T + bias) * gamma + beta + post_add[row % post_rows, :]   -> bf16 (+ lo)
+ * without materialising the fp32 [M,N] product.  Supported: n in {256,512,768,896,1024}, k % 32 == 0, k <= 256
+ * (else LVQ_EUNSUPPORTED: callers use lvq_gemm_bf16 + lvq_layernorm). */
+int lvq_gemm_ln_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,
+                     const float *gamma, const float *beta, float eps, const float *post_add, int64_t post_rows,
+                     int64_t m, int n, int k, int64_t lda, int64_t ldw, lvq_bf16 *y_bf16, lvq_bf16 *y_lo, lvq_stream_t stream);
+
 /* fp32 -> bf16 (round-to-nearest-even) with optional lo part (x - bf16(x)) for the bf16x3 mode. */
 int lvq_cast_bf16(const float *x, int64_t n, lvq_bf16 *hi, lvq_bf16 *lo, lvq_stream_t stream);
 /* out = (hi + lo) * alpha as fp32 (lo may be NULL): hands attention outputs back to fp32 callers. */

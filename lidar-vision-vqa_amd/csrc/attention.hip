@@ -68,15 +68,19 @@ __device__ __forceinline__ float max_over_groups(float x) {
 // invariant and whose tile offset is a scalar (hardware bounds check = zero fill past Nkv), exponentials are raw
 // v_exp_f32, the row maximum uses v_max3 chains + two permlane swaps, the row sum is an extra MFMA row, and
 // bias / causal / ragged-tile handling lives in a separate slow path taken only by the tiles that need it.
-template <int DHP, int NSPLIT, int QT>
-__global__ void __launch_bounds__(256) k_attn(AttnArgs a) {
+// NW = waves per workgroup (4, 8 or 12): all of them share one K/V stream, so a 12-wave workgroup (192 queries)
+// reads K/V from HBM/MALL three times less often than three 4-wave workgroups (PMC: 26 GB per launch = 8x the
+// algorithmic bytes with NW = 4 on the 576 x 262144 shape).
+template <int DHP, int NSPLIT, int QT, int NW>
+__global__ void __launch_bounds__(NW * 64) k_attn(AttnArgs a) {
     constexpr int NS = (NSPLIT == 3) ? 2 : 1;
     constexpr int KROW = DHP + 8;       // bf16 elements per K / V row (+16 B pad: odd multiple of 16 B)
     constexpr int NC = DHP / 32;        // 32-wide k chunks of the head dim
     constexpr int ND = DHP / 16;        // 16-wide output tiles of the head dim
     constexpr int QW = 16 * QT;         // queries per wave
     constexpr int CH = DHP / 8;                      // 16-byte chunks per row
-    constexpr int NLD = (KVB * CH + 255) / 256;      // chunks per thread per operand
+    constexpr int NT = NW * 64;
+    constexpr int NLD = (KVB * CH + NT - 1) / NT;    // chunks per thread per operand
     constexpr int TILE_E = 2 * NS * KVB * KROW;      // bf16 elements of one K+V stage
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     // per stage: Ks [NS][KVB][KROW] row-major keys | Vs [NS][KVB][KROW] row-major values (read transposed by
@@ -87,7 +91,7 @@ __global__ void __launch_bounds__(256) k_attn(AttnArgs a) {
     const int grp = blockIdx.x / a.nqt, qtile = blockIdx.x - grp * a.nqt;
     const int sp = grp % a.nsplit, h = (grp / a.nsplit) % a.H, b = grp / (a.nsplit * a.H);
     const int hk = h / (a.H / a.Hkv);
-    const int q0 = qtile * (4 * QW) + wid * QW;
+    const int q0 = qtile * (NW * QW) + wid * QW;
     const float cexp = a.scale * 1.4426950408889634f;   // scores are exponentiated in the log2 domain
 
     // Q fragments (B operand of S^T = K Q^T): lane supplies Q[q0 + qt*16 + l15][c*32 + 8g .. +7]
@@ -126,7 +130,7 @@ __global__ void __launch_bounds__(256) k_attn(AttnArgs a) {
     const int t0 = sp * tps;
     int t1 = t0 + tps < n_tiles ? t0 + tps : n_tiles;
     if (a.causal) {   // keys beyond the last visible one of this workgroup's last query are never needed
-        int qlast = qtile * (4 * QW) + 4 * QW - 1;
+        int qlast = qtile * (NW * QW) + NW * QW - 1;
         if (qlast > a.Nq - 1) qlast = a.Nq - 1;
         const int tl = (qlast + a.Nkv - a.Nq) / KVB + 1;
         if (t1 > tl) t1 = tl;
@@ -150,7 +154,7 @@ __global__ void __launch_bounds__(256) k_attn(AttnArgs a) {
     bool live[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-        const int e = tid + 256 * i, r = e / CH, kk = (e - r * CH) * 8;
+        const int e = tid + NT * i, r = e / CH, kk = (e - r * CH) * 8;
         live[i] = (e < KVB * CH) && (kk < a.dh);        // head-dim padding chunks stay zero
         koff[i] = (uint32_t)((r * a.ldk + kk) * 2);
         voff[i] = (uint32_t)((r * a.ldv + kk) * 2);
@@ -175,7 +179,7 @@ __global__ void __launch_bounds__(256) k_attn(AttnArgs a) {
         uint16_t *kd = smem + buf * TILE_E, *vd = kd + NS * KVB * KROW;
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            if (tid + 256 * i < KVB * CH) {
+            if (tid + NT * i < KVB * CH) {
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     *reinterpret_cast<i32x4 *>(kd + s * KVB * KROW + lso[i]) = sk[s][i];
@@ -395,7 +399,7 @@ __global__ void __launch_bounds__(256) k_attn_combine(AttnArgs a) {
 }
 
 // launch geometry shared by lvq_attention_workspace_bytes and lvq_attention_bf16
-struct AttnPlan { int qt, nqt, nsplit; };
+struct AttnPlan { int qt, nw, nqt, nsplit; };
 AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split) {
     AttnPlan p;
     const int dhp = (dh + 31) / 32 * 32;
@@ -409,7 +413,19 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split) 
         const int f = atoi(ev);
         if ((f == 1 || f == 2 || f == 4) && f <= qmax) p.qt = f;
     }
-    p.nqt = (nq + 64 * p.qt - 1) / (64 * p.qt);
+    // waves per workgroup: long K/V streams are bandwidth-bound on re-reads -> as many queries per stream as fit
+    p.nw = 4;
+    if (p.qt == 1 && nkv >= 4096 && dhp <= 64) {
+        for (int nw : {12, 8}) {
+            const int64_t tile = 16 * nw, padded = (nq + tile - 1) / tile * tile;
+            if ((padded - nq) * 8 <= nq) { p.nw = nw; break; }
+        }
+    }
+    if (const char *ev = getenv("LVQ_ATTN_NW")) {
+        const int f = atoi(ev);
+        if ((f == 4 || f == 8 || f == 12) && p.qt == 1 && dhp <= 64) p.nw = f;
+    }
+    p.nqt = (nq + 16 * p.nw * p.qt - 1) / (16 * p.nw * p.qt);
     const int64_t base = (int64_t)p.nqt * n_heads * batch;
     const int n_tiles = (nkv + KVB - 1) / KVB;
     // enough workgroups for >= ~5 dispatch rounds (3 resident workgroups per CU): with ~1.1 rounds the straggler round
@@ -422,15 +438,15 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split) 
     return p;
 }
 
-template <int DHP, int NSPLIT, int QT> int launch_attn_qt(AttnArgs &a, hipStream_t st) {
+template <int DHP, int NSPLIT, int QT, int NW> int launch_attn_qt(AttnArgs &a, hipStream_t st) {
     constexpr int NS = (NSPLIT == 3) ? 2 : 1;
     const size_t lds = (size_t)(2 * 2 * NS * KVB * (DHP + 8)) * sizeof(uint16_t);   // two K+V stages
     if (lds > 64 * 1024)
-        hipFuncSetAttribute((const void *)k_attn<DHP, NSPLIT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute((const void *)k_attn<DHP, NSPLIT, QT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int64_t nwg = (int64_t)a.B * a.H * a.nsplit * a.nqt;
     if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
     dim3 grid((unsigned)nwg);
-    hipLaunchKernelGGL((k_attn<DHP, NSPLIT, QT>), grid, dim3(256), lds, st, a);
+    hipLaunchKernelGGL((k_attn<DHP, NSPLIT, QT, NW>), grid, dim3(NW * 64), lds, st, a);
     if (a.nsplit > 1) {
         const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
         hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
@@ -438,10 +454,13 @@ template <int DHP, int NSPLIT, int QT> int launch_attn_qt(AttnArgs &a, hipStream
     return lvq_launch_status();
 }
 
-template <int DHP, int NSPLIT> int launch_attn(AttnArgs &a, int qt, hipStream_t st) {
-    if (DHP <= 64 && NSPLIT == 1 && qt == 4) return launch_attn_qt<DHP, NSPLIT, (DHP <= 64 && NSPLIT == 1) ? 4 : 1>(a, st);
-    if (!(DHP > 64 && NSPLIT == 3) && qt >= 2) return launch_attn_qt<DHP, NSPLIT, (DHP > 64 && NSPLIT == 3) ? 1 : 2>(a, st);
-    return launch_attn_qt<DHP, NSPLIT, 1>(a, st);
+template <int DHP, int NSPLIT> int launch_attn(AttnArgs &a, const AttnPlan &pl, hipStream_t st) {
+    if (pl.qt == 1 && DHP <= 64) {        // the many-wave forms exist for the head dims of the VAT blocks (<= 64)
+        if (pl.nw == 12) return launch_attn_qt<DHP, NSPLIT, 1, (DHP <= 64) ? 12 : 4>(a, st);
+        if (pl.nw == 8) return launch_attn_qt<DHP, NSPLIT, 1, (DHP <= 64) ? 8 : 4>(a, st);
+    }
+    if (!(DHP > 64 && NSPLIT == 3) && pl.qt >= 2) return launch_attn_qt<DHP, NSPLIT, (DHP > 64 && NSPLIT == 3) ? 1 : 2, 4>(a, st);
+    return launch_attn_qt<DHP, NSPLIT, 1, 4>(a, st);
 }
 
 // row softmax for the split (large head-dim) path: p = softmax(s*scale + bias, causal) -> bf16 hi/lo
@@ -548,17 +567,17 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
         }
         if (!split) {
             switch (dhp) {
-                case 32: return launch_attn<32, 1>(a, pl.qt, st);
-                case 64: return launch_attn<64, 1>(a, pl.qt, st);
-                case 96: return launch_attn<96, 1>(a, pl.qt, st);
-                default: return launch_attn<128, 1>(a, pl.qt, st);
+                case 32: return launch_attn<32, 1>(a, pl, st);
+                case 64: return launch_attn<64, 1>(a, pl, st);
+                case 96: return launch_attn<96, 1>(a, pl, st);
+                default: return launch_attn<128, 1>(a, pl, st);
             }
         } else {
             switch (dhp) {
-                case 32: return launch_attn<32, 3>(a, pl.qt, st);
-                case 64: return launch_attn<64, 3>(a, pl.qt, st);
-                case 96: return launch_attn<96, 3>(a, pl.qt, st);
-                default: return launch_attn<128, 3>(a, pl.qt, st);
+                case 32: return launch_attn<32, 3>(a, pl, st);
+                case 64: return launch_attn<64, 3>(a, pl, st);
+                case 96: return launch_attn<96, 3>(a, pl, st);
+                default: return launch_attn<128, 3>(a, pl, st);
             }
         }
     }

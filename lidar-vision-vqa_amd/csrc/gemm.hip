@@ -508,6 +508,153 @@ __global__ void __launch_bounds__(512) k_gemm_persist(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Row-complete GEMM with LayerNorm fused into the epilogue (VATLiDAR token path, vat_lidar.py:222-248):
+//     Y = LayerNorm(A W^T + bias) * gamma + beta + post[row % post_rows]        -> bf16 (hi, lo)
+// One workgroup owns 64 rows x ALL N columns (N <= 1024), so the row statistics never leave registers and the
+// fp32 [M, N] intermediate (3.2 GB per 4 scenes at d = 768) is never written.  Meant for SMALL K (the 1x1 conv
+// has K = C_in = 64..128): W is streamed through LDS in 32-wide K steps, single-buffered (2 workgroups per CU
+// overlap); the op is bound by the bf16 store + the positional-table read, not by MFMA.
+// Wave w owns rows 16w..16w+15 and all NT16 = N/16 column tiles (acc = NT16 x 4 registers).
+// ---------------------------------------------------------------------------------------------------------
+struct GemmLnArgs {
+    const uint16_t *a[3];
+    const uint16_t *w[3];
+    int nseg;
+    const float *bias, *gamma, *beta, *post;
+    int64_t post_rows;
+    float eps;
+    int64_t M;
+    int N, K;
+    int64_t lda, ldw;
+    uint16_t *y16, *y16lo;
+};
+
+template <int NT16>
+__global__ void __launch_bounds__(256, (NT16 <= 48 ? 2 : 1)) k_gemm_ln(GemmLnArgs g) {
+    constexpr int N = NT16 * 16;
+    constexpr int WROW = 40;                         // bf16 elements per staged row (32 + 8 pad: 80-byte rows, odd x 16 B)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *sw = reinterpret_cast<uint16_t *>(smem);          // [N][WROW]
+    uint16_t *sa = sw + N * WROW;                                 // [64][WROW]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    const int nk = g.K / 32;
+
+    f32x4 acc[NT16];
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int it = 0; it < nk * g.nseg; ++it) {
+        const int seg = it / nk, k0 = (it - seg * nk) * 32;
+        const uint16_t *A = g.a[seg], *W = g.w[seg];
+        // stage W[:, k0:k0+32] (N rows x 4 chunks) and A[m0:m0+64, k0:k0+32]
+        for (int e = tid; e < N * 4; e += 256) {
+            const int r = e >> 2, ch = e & 3;
+            *reinterpret_cast<uint4 *>(sw + r * WROW + ch * 8) = *reinterpret_cast<const uint4 *>(W + (int64_t)r * g.ldw + k0 + ch * 8);
+        }
+        {
+            const int r = tid >> 2, ch = tid & 3;
+            int64_t gm = m0 + r;
+            gm = gm < g.M ? gm : g.M - 1;
+            *reinterpret_cast<uint4 *>(sa + r * WROW + ch * 8) = *reinterpret_cast<const uint4 *>(A + gm * g.lda + k0 + ch * 8);
+        }
+        __syncthreads();
+        const bf16x8 af = *reinterpret_cast<const bf16x8 *>(sa + (wid * 16 + l15) * WROW + g4 * 8);
+#pragma unroll
+        for (int j = 0; j < NT16; ++j) {
+            const bf16x8 bfr = *reinterpret_cast<const bf16x8 *>(sw + (j * 16 + l15) * WROW + g4 * 8);
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr, acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- bias, then LayerNorm statistics: lane (l15, g4) holds rows 4*g4 + r, columns 16 j + l15 ----
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NT16; ++j) {
+        const float b = g.bias ? g.bias[j * 16 + l15] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[j][r] += b; s[r] += acc[j][r]; }
+    }
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) s[r] += __shfl_xor(s[r], o);
+        mean[r] = s[r] / (float)N;
+        s[r] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NT16; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[j][r] -= mean[r]; s[r] = fmaf(acc[j][r], acc[j][r], s[r]); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) s[r] += __shfl_xor(s[r], o);
+        rstd[r] = 1.0f / sqrtf(s[r] / (float)N + g.eps);
+    }
+
+    // ---- epilogue in 64-column chunks through a wave-private slab: 16 rows x 64 columns -> 16-byte stores ----
+    constexpr int LDE = 68;
+    float *ep = reinterpret_cast<float *>(smem) + wid * (16 * LDE);
+#pragma unroll
+    for (int cc = 0; cc < NT16 / 4; ++cc) {          // fully unrolled: the accumulator tiles need static register indices
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ep[(g4 * 4 + r) * LDE + jj * 16 + l15] = acc[cc * 4 + jj][r] * rstd[r];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int q = p * 64 + lane, rr = q >> 3, c8 = q & 7;
+            const int64_t row = m0 + wid * 16 + rr;
+            const int col = cc * 64 + c8 * 8;
+            float v[8];
+            *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8);
+            *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8 + 4);
+            if (row < g.M) {
+                const float4 g0 = *reinterpret_cast<const float4 *>(g.gamma + col), g1 = *reinterpret_cast<const float4 *>(g.gamma + col + 4);
+                v[0] *= g0.x; v[1] *= g0.y; v[2] *= g0.z; v[3] *= g0.w; v[4] *= g1.x; v[5] *= g1.y; v[6] *= g1.z; v[7] *= g1.w;
+                if (g.beta) {
+                    const float4 b0 = *reinterpret_cast<const float4 *>(g.beta + col), b1 = *reinterpret_cast<const float4 *>(g.beta + col + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (g.post) {
+                    const float *t = g.post + (row % g.post_rows) * N + col;
+                    const float4 t0 = *reinterpret_cast<const float4 *>(t), t1 = *reinterpret_cast<const float4 *>(t + 4);
+                    v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+                }
+                const int64_t o = row * N + col;
+                const uint4 hb = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+                *reinterpret_cast<uint4 *>(g.y16 + o) = hb;
+                if (g.y16lo) {
+                    const uint4 lb = make_uint4(pack_bf16(v[0] - __uint_as_float(hb.x << 16), v[1] - __uint_as_float(hb.x & 0xffff0000u)),
+                                                pack_bf16(v[2] - __uint_as_float(hb.y << 16), v[3] - __uint_as_float(hb.y & 0xffff0000u)),
+                                                pack_bf16(v[4] - __uint_as_float(hb.z << 16), v[5] - __uint_as_float(hb.z & 0xffff0000u)),
+                                                pack_bf16(v[6] - __uint_as_float(hb.w << 16), v[7] - __uint_as_float(hb.w & 0xffff0000u)));
+                    *reinterpret_cast<uint4 *>(g.y16lo + o) = lb;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <int NT16> int launch_gemm_ln(const GemmLnArgs &g, hipStream_t st) {
+    const size_t lds = (size_t)(NT16 * 16 + 64) * 40 * sizeof(uint16_t);      // >= 4 waves x 16 x 68 floats (17 KB) for every NT16 >= 12
+    static bool done = false;
+    if (!done && lds > 64 * 1024) {
+        hipFuncSetAttribute((const void *)k_gemm_ln<NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        done = true;
+    }
+    hipLaunchKernelGGL(k_gemm_ln<NT16>, dim3((unsigned)lvq_cdiv(g.M, 64)), dim3(256), lds, st, g);
+    return lvq_launch_status();
+}
+
 __global__ void __launch_bounds__(256) k_cast_bf16(const float *__restrict__ x, int64_t n, uint16_t *__restrict__ hi,
                                                    uint16_t *__restrict__ lo) {
     int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -638,4 +785,33 @@ extern "C" int lvq_bf16_to_f32(const lvq_bf16 *hi, const lvq_bf16 *lo, int64_t n
     if (n == 0) return LVQ_OK;
     hipLaunchKernelGGL(k_bf16_to_f32, dim3((unsigned)lvq_cdiv(n, 256)), dim3(256), 0, lvq_s(stream), hi, lo, n, alpha, out);
     return lvq_launch_status();
+}
+
+extern "C" int lvq_gemm_ln_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,
+                                const float *gamma, const float *beta, float eps, const float *post_add, int64_t post_rows,
+                                int64_t m, int n, int k, int64_t lda, int64_t ldw, lvq_bf16 *y_bf16, lvq_bf16 *y_lo,
+                                lvq_stream_t stream) {
+    if (m < 0 || n <= 0 || k <= 0 || !a || !w || !gamma || !y_bf16) return LVQ_EINVAL;
+    if ((a_lo == nullptr) != (w_lo == nullptr)) return LVQ_EINVAL;
+    if (post_add && post_rows <= 0) return LVQ_EINVAL;
+    if (m == 0) return LVQ_OK;
+    if ((k & 31) || k > 256 || (lda & 7) || (ldw & 7) || lda < k || ldw < k) return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)a_lo | (uintptr_t)w_lo | (uintptr_t)bias | (uintptr_t)gamma | (uintptr_t)beta |
+         (uintptr_t)post_add | (uintptr_t)y_bf16 | (uintptr_t)y_lo) & 15)
+        return LVQ_EUNSUPPORTED;
+    if (lvq_cdiv(m, 64) > 0x7fffffff) return LVQ_EUNSUPPORTED;
+    GemmLnArgs g;
+    g.nseg = a_lo ? 3 : 1;
+    g.a[0] = a; g.w[0] = w; g.a[1] = a; g.w[1] = w_lo; g.a[2] = a_lo; g.w[2] = w;
+    g.bias = bias; g.gamma = gamma; g.beta = beta; g.post = post_add; g.post_rows = post_rows; g.eps = eps;
+    g.M = m; g.N = n; g.K = k; g.lda = lda; g.ldw = ldw; g.y16 = y_bf16; g.y16lo = y_lo;
+    hipStream_t st = lvq_s(stream);
+    switch (n) {   // row-complete tiles: one instantiation per supported d_model
+        case 256: return launch_gemm_ln<16>(g, st);
+        case 512: return launch_gemm_ln<32>(g, st);
+        case 768: return launch_gemm_ln<48>(g, st);
+        case 896: return launch_gemm_ln<56>(g, st);
+        case 1024: return launch_gemm_ln<64>(g, st);
+        default: return LVQ_EUNSUPPORTED;
+    }
 }

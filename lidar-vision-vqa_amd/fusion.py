@@ -241,9 +241,13 @@ class VATLiDAR(_HipModule):
         B, C, H, W = bev.shape
         split = self._split()
         t = ops.dwconv3x3_gelu(_f32(bev), self.refine[0].weight.detach().reshape(C, 9).contiguous(), self.refine[0].bias, split)
+        pe = self._pe_table(H, W, bev.device)
+        if ops.linear_ln_supported(self.d_model, C):
+            # 1x1 conv + LayerNorm + positional table in one row-complete kernel: no fp32 [B*HW, d] round trip
+            return ops.linear_ln(t, self._w(self.proj.weight), self.proj.bias, self.norm_tokens.weight, self.norm_tokens.bias,
+                                 self.norm_tokens.eps, post=pe, tag="bev_proj_ln")
         x32, _ = ops.linear(t, self._w(self.proj.weight), self.proj.bias, out_f32=True)
-        _, x = ops.layernorm(x32, self.norm_tokens.weight, self.norm_tokens.bias, self.norm_tokens.eps, split,
-                             post=self._pe_table(H, W, bev.device))
+        _, x = ops.layernorm(x32, self.norm_tokens.weight, self.norm_tokens.bias, self.norm_tokens.eps, split, post=pe)
         return x
 
     def forward(self, bev: torch.Tensor) -> torch.Tensor:

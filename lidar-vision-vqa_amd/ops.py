@@ -211,3 +211,27 @@ def cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
     rc = F.lib().lvq_cross_entropy(F.ptr(logits), F.ptr(labels), F.i64(rows), F.cint(vocab), F.ptr(acc), F.stream_ptr(logits.device))
     F.check(rc, "lvq_cross_entropy")
     return acc[0] / acc[1]
+
+
+GEMM_LN_WIDTHS = (256, 512, 768, 896, 1024)
+
+
+def linear_ln_supported(n: int, k: int) -> bool:
+    return n in GEMM_LN_WIDTHS and k % 32 == 0 and k <= 256
+
+
+def linear_ln(a: BF, w: BF, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: Optional[torch.Tensor], eps: float,
+              post: Optional[torch.Tensor] = None, tag: Optional[str] = None) -> BF:
+    """LayerNorm(a @ w.T + bias) * gamma + beta + post[row % rows] -> BF, no fp32 [M,N] intermediate (lvq_gemm_ln_bf16)."""
+    ah, al = a
+    wh, wl = w
+    m, k = ah.shape
+    n = wh.shape[0]
+    split = al is not None
+    yh, yl = _bf_empty((m, n), ah.device, split)
+    with region(tag, ah.device):
+        rc = F.lib().lvq_gemm_ln_bf16(F.ptr(ah), F.ptr(al), F.ptr(wh), F.ptr(wl), F.ptr(bias), F.ptr(gamma), F.ptr(beta), F.cfloat(eps),
+                                      F.ptr(post), F.i64(post.shape[0] if post is not None else 0), F.i64(m), F.cint(n), F.cint(k),
+                                      F.i64(k), F.i64(k), F.ptr(yh), F.ptr(yl), F.stream_ptr(ah.device))
+    F.check(rc, f"lvq_gemm_ln_bf16 (m={m}, n={n}, k={k})")
+    return yh, yl

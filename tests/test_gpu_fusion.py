@@ -91,6 +91,26 @@ def test_layernorm(rows, d):
     assert (o.to_f32(ybf).double().cpu() - ref).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("m,n,k", [(64, 768, 64), (1000, 768, 64), (129, 896, 128), (300, 256, 32), (70, 1024, 256), (4096, 512, 96)])
+@pytest.mark.parametrize("split", [False, True])
+def test_gemm_ln_fused(m, n, k, split):
+    """Row-complete Linear + LayerNorm + positional table (lvq_gemm_ln_bf16) vs fp64."""
+    o = ops()
+    a = torch.from_numpy(synth.randn((m, k), 41)).to(DEV)
+    w = torch.from_numpy(synth.randn((n, k), 42, 0.2)).to(DEV)
+    bias = torch.from_numpy(synth.randn((n,), 43)).to(DEV)
+    gam = torch.from_numpy(synth.randn((n,), 44)).to(DEV) + 1.0
+    bet = torch.from_numpy(synth.randn((n,), 45)).to(DEV)
+    post = torch.from_numpy(synth.randn((37, n), 46)).to(DEV)
+    if not split:
+        a, w = bf_round(a), bf_round(w)
+    y = o.linear_ln(o.cast(a, split), o.cast(w, split), bias, gam, bet, 1e-5, post=post)
+    z = a.double().cpu() @ w.double().cpu().t() + bias.double().cpu()
+    ref = torch.nn.functional.layer_norm(z, (n,), gam.double().cpu(), bet.double().cpu(), 1e-5) + post.double().cpu()[torch.arange(m) % 37]
+    err = (o.to_f32(y).double().cpu() - ref).abs().max().item()
+    assert err < (2.0 ** -8 * ref.abs().max().item() if not split else 3e-4), err      # plain mode: output rounded to bf16 (one ulp)
+
+
 ATT_CASES = [
     # B, H, Hkv, nq, nkv, dh, bias, causal
     (1, 2, 2, 16, 64, 64, False, False),

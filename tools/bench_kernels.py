@@ -86,6 +86,21 @@ def bench_norm():
         print(f"layernorm rows={rows} d={d}: {t:.4f} ms  {by / t / 1e6:.0f} GB/s algorithmic")
 
 
+def bench_projln():
+    m, n, k = 4 * 262144, 768, 64
+    a = torch.randn(m, k, device=DEV); w = torch.randn(n, k, device=DEV) * 0.1
+    bias, g, b = torch.randn(n, device=DEV), torch.randn(n, device=DEV), torch.randn(n, device=DEV)
+    post = torch.randn(262144, n, device=DEV)
+    for split in (False, True):
+        ab, wb = ops.cast(a, split), ops.cast(w, split)
+        t, _ = timeit(lambda: ops.linear_ln(ab, wb, bias, g, b, 1e-5, post=post), iters=5)
+        def unfused():
+            x32, _ = ops.linear(ab, wb, bias, out_f32=True)
+            return ops.layernorm(x32, g, b, 1e-5, split, post=post)
+        t2, _ = timeit(unfused, iters=5)
+        print(f"proj+LN+PE (M={m}, N={n}, K={k}) {'x3' if split else 'bf16'}: fused {t:.3f} ms, unfused {t2:.3f} ms")
+
+
 def bench_vox():
     rng = list(synth.PC_RANGE_NUSC)
     for S, n, vs, T, mv, what in [(8, 65536, synth.VOXEL_01, 10, 160000, "cfg-3 0.1m"), (1, 32768, synth.VOXEL_01, 10, 60000, "cfg-2 0.1m"),
@@ -138,4 +153,4 @@ if __name__ == "__main__":
     for w in which:
         print(f"==== {w} ====")
         {"gemm": bench_gemm, "attn": bench_attn, "norm": bench_norm, "vox": bench_vox, "attn1": bench_attn_one,
-         "gemm1": bench_gemm_one}[w]()
+         "gemm1": bench_gemm_one, "projln": bench_projln}[w]()
