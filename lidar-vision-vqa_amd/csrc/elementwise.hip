@@ -125,47 +125,75 @@ bool launch_norm_vec(const float *x, const float *add, int add_rows, int add_gro
     return false;
 }
 
-// depthwise 3x3 (pad 1) + GELU: block = 32 channels x one image row segment of 64 pixels
+// depthwise 3x3 (pad 1) + GELU, NCHW fp32 -> token-major bf16.  Block = 64 channels x 4 rows x 32 pixels: the 6 x 34
+// input halo is loaded once (1.6x re-read instead of 3x), every thread slides a 3-row window down 4 output rows for
+// 8 channels, and the [pixel][channel] outputs leave through LDS as whole 128-byte token rows (16-byte stores).
+constexpr int DW_C = 64, DW_RY = 2, DW_PX = 32;
 __global__ void __launch_bounds__(256) k_dwconv3x3_gelu(const float *__restrict__ bev, const float *__restrict__ w9,
                                                         const float *__restrict__ bias, int C, int H, int W,
                                                         uint16_t *__restrict__ thi, uint16_t *__restrict__ tlo) {
-    __shared__ float tile[32][3][68];       // [channel][row y-1..y+1][x0-1 .. x0+64] (+pad)
-    __shared__ float outv[64][33];          // [pixel][channel] (+1 pad)
-    const int x0 = blockIdx.x * 64, y = blockIdx.y;
-    const int cblocks = (C + 31) / 32;
-    const int b = blockIdx.z / cblocks, c0 = (blockIdx.z % cblocks) * 32;
+    __shared__ float tile[DW_C][DW_RY + 2][DW_PX + 4];                       // 64 x 4 x 36 floats = 36 KB (+ 2 x 9 KB out: 2-3 blocks/CU)
+    __shared__ __attribute__((aligned(16))) uint16_t oh[DW_RY][DW_PX][DW_C + 8];   // +16 B pad per pixel row
+    __shared__ __attribute__((aligned(16))) uint16_t ol[DW_RY][DW_PX][DW_C + 8];
+    const int x0 = blockIdx.x * DW_PX, y0 = blockIdx.y * DW_RY;
+    const int cblocks = (C + DW_C - 1) / DW_C;
+    const int b = blockIdx.z / cblocks, c0 = (blockIdx.z % cblocks) * DW_C;
     const int tid = threadIdx.x;
-    for (int e = tid; e < 32 * 3 * 66; e += 256) {
-        const int xx = e % 66, r = (e / 66) % 3, c = e / (66 * 3);
-        const int gx = x0 + xx - 1, gy = y + r - 1, gc = c0 + c;
-        float v = 0.f;
-        if (gc < C && gx >= 0 && gx < W && gy >= 0 && gy < H) v = bev[(((int64_t)b * C + gc) * H + gy) * W + gx];
-        tile[c][r][xx] = v;
+    constexpr int ROWE = DW_PX + 2, PLANE = (DW_RY + 2) * ROWE;              // 34, 204
+    // 8 independent loads in flight per thread before the LDS writes (a load->store loop waits one HBM latency per element)
+    for (int e0 = tid; e0 < DW_C * PLANE; e0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256;
+            const int c = e / PLANE, rem = e - c * PLANE, r = rem / ROWE, xx = rem - r * ROWE;
+            const int gx = x0 + xx - 1, gy = y0 + r - 1, gc = c0 + c;
+            v[u] = 0.f;
+            if (e < DW_C * PLANE && gc < C && gx >= 0 && gx < W && gy >= 0 && gy < H) v[u] = bev[(((int64_t)b * C + gc) * H + gy) * W + gx];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + u * 256;
+            const int c = e / PLANE, rem = e - c * PLANE, r = rem / ROWE, xx = rem - r * ROWE;
+            if (e < DW_C * PLANE) tile[c][r][xx] = v[u];
+        }
     }
     __syncthreads();
-    for (int e = tid; e < 32 * 64; e += 256) {
-        const int xx = e & 63, c = e >> 6, gc = c0 + c;
-        float acc = 0.f;
-        if (gc < C) {
-            const float *wk = w9 + gc * 9;
-            acc = bias ? bias[gc] : 0.f;
+    const int xx = tid & 31, cg = tid >> 5;
+#pragma unroll 1
+    for (int i = 0; i < DW_C / 8; ++i) {
+        const int c = cg * 8 + i, gc = c0 + c;
+        float wk[9], bs = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k] = gc < C ? w9[gc * 9 + k] : 0.f;
+        if (gc < C && bias) bs = bias[gc];
+        float win[DW_RY + 2][3];
+#pragma unroll
+        for (int r = 0; r < DW_RY + 2; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) win[r][k] = tile[c][r][xx + k];
+#pragma unroll
+        for (int ry = 0; ry < DW_RY; ++ry) {
+            float acc = bs;
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int s = 0; s < 3; ++s) acc = fmaf(tile[c][r][xx + s], wk[r * 3 + s], acc);
+                for (int k = 0; k < 3; ++k) acc = fmaf(win[ry + r][k], wk[r * 3 + k], acc);
             acc = gelu_erf(acc);
+            const uint16_t h = f32_to_bf16(acc);
+            oh[ry][xx][c] = h;
+            ol[ry][xx][c] = f32_to_bf16(acc - bf16_to_f32(h));
         }
-        outv[xx][c] = acc;
     }
     __syncthreads();
-    for (int e = tid; e < 64 * 32; e += 256) {
-        const int c = e & 31, xx = e >> 5, gx = x0 + xx, gc = c0 + c;
-        if (gx < W && gc < C) {
-            const int64_t o = ((int64_t)b * H * W + (int64_t)y * W + gx) * C + gc;
-            const float v = outv[xx][c];
-            const uint16_t h = f32_to_bf16(v);
-            thi[o] = h;
-            if (tlo) tlo[o] = f32_to_bf16(v - bf16_to_f32(h));
+    const int nc = (C - c0) < DW_C ? (C - c0) : DW_C;            // channels of this block (multiple of 8)
+    for (int e = tid; e < DW_RY * DW_PX * (DW_C / 8); e += 256) {
+        const int ch = e & 7, px = (e >> 3) & (DW_PX - 1), ry = e >> 8;   // 8 chunks x 32 pixels = 256 per output row
+        const int gx = x0 + px, gy = y0 + ry;
+        if (gx < W && gy < H && ch * 8 < nc) {
+            const int64_t o = ((int64_t)b * H * W + (int64_t)gy * W + gx) * C + c0 + ch * 8;
+            *reinterpret_cast<uint4 *>(thi + o) = *reinterpret_cast<const uint4 *>(&oh[ry][px][ch * 8]);
+            if (tlo) *reinterpret_cast<uint4 *>(tlo + o) = *reinterpret_cast<const uint4 *>(&ol[ry][px][ch * 8]);
         }
     }
 }
@@ -272,9 +300,11 @@ extern "C" int lvq_rmsnorm(const float *x, const float *gamma, float eps, int64_
 extern "C" int lvq_dwconv3x3_gelu(const float *bev, const float *w9, const float *bias, int batch, int ch, int h, int w,
                                   lvq_bf16 *tokens_hi, lvq_bf16 *tokens_lo, lvq_stream_t stream) {
     if (batch <= 0 || ch <= 0 || h <= 0 || w <= 0 || !bev || !w9 || !tokens_hi) return LVQ_EINVAL;
-    const int cblocks = (ch + 31) / 32;
-    if ((int64_t)batch * cblocks > 65535 || h > 65535) return LVQ_EUNSUPPORTED;
-    dim3 grid((unsigned)lvq_cdiv(w, 64), (unsigned)h, (unsigned)(batch * cblocks));
+    if (ch % 8) return LVQ_EUNSUPPORTED;                      // 16-byte token stores
+    if (((uintptr_t)tokens_hi | (uintptr_t)tokens_lo) & 15) return LVQ_EUNSUPPORTED;
+    const int cblocks = (ch + DW_C - 1) / DW_C;
+    if ((int64_t)batch * cblocks > 65535 || lvq_cdiv(h, DW_RY) > 65535) return LVQ_EUNSUPPORTED;
+    dim3 grid((unsigned)lvq_cdiv(w, DW_PX), (unsigned)lvq_cdiv(h, DW_RY), (unsigned)(batch * cblocks));
     hipLaunchKernelGGL(k_dwconv3x3_gelu, grid, dim3(256), 0, lvq_s(stream), bev, w9, bias, ch, h, w, tokens_hi, tokens_lo);
     return lvq_launch_status();
 }

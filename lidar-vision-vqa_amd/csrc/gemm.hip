@@ -549,9 +549,21 @@ __global__ void __launch_bounds__(256, (NT16 <= 48 ? 2 : 1)) k_gemm_ln(GemmLnArg
         const int seg = it / nk, k0 = (it - seg * nk) * 32;
         const uint16_t *A = g.a[seg], *W = g.w[seg];
         // stage W[:, k0:k0+32] (N rows x 4 chunks) and A[m0:m0+64, k0:k0+32]
-        for (int e = tid; e < N * 4; e += 256) {
-            const int r = e >> 2, ch = e & 3;
-            *reinterpret_cast<uint4 *>(sw + r * WROW + ch * 8) = *reinterpret_cast<const uint4 *>(W + (int64_t)r * g.ldw + k0 + ch * 8);
+        // N*4 chunks / 256 threads = NT16/4 per thread, issued in batches of 4 independent loads before the LDS writes
+        // (a load->store loop pays one L2 latency per iteration)
+#pragma unroll
+        for (int b0 = 0; b0 < NT16 / 4; b0 += 4) {
+            uint4 tmp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + (b0 + u) * 256, r = e >> 2, ch = e & 3;
+                if (b0 + u < NT16 / 4) tmp[u] = *reinterpret_cast<const uint4 *>(W + (int64_t)r * g.ldw + k0 + ch * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = tid + (b0 + u) * 256, r = e >> 2, ch = e & 3;
+                if (b0 + u < NT16 / 4) *reinterpret_cast<uint4 *>(sw + r * WROW + ch * 8) = tmp[u];
+            }
         }
         {
             const int r = tid >> 2, ch = tid & 3;
