@@ -22,6 +22,14 @@
 //   * divisions are IEEE fp32 (-fhip-fp32-correctly-rounded-divide-sqrt, no fast-math) so that
 //     floor((p - lo) / vs) matches the CPU bit for bit.
 #include "common.h"
+#include <stdlib.h>
+
+// slab-binned fast paths (voxel_binned.hip); they return LVQ_EUNSUPPORTED for shapes they do not take
+size_t lvq_binned_dynamic_workspace_bytes(int64_t n);
+int lvq_binned_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_size, const float *range_host,
+                                const float *vsize_host, const int32_t *grid_host, int ndim, int32_t *unq_inv, int32_t *pt_coords,
+                                int32_t *unq_key, int32_t *unq_cnt, int32_t *coords_bzyx, int32_t *counts, void *ws, size_t ws_bytes,
+                                hipStream_t st);
 
 namespace {
 
@@ -614,7 +622,8 @@ extern "C" size_t lvq_voxelize_dynamic_workspace_bytes(int64_t n_points, int bat
     SizerAdapter a;
     DynWs w;
     dyn_layout(a, w, n_points, ks);
-    return a.s.total();
+    const size_t binned = lvq_binned_dynamic_workspace_bytes(n_points);
+    return a.s.total() > binned ? a.s.total() : binned;
 }
 
 extern "C" int lvq_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_size, const float *range_host,
@@ -635,6 +644,11 @@ extern "C" int lvq_voxelize_dynamic(const float *pts, int64_t n, int c, int batc
         return lvq_launch_status();
     }
     if (!pts || !unq_inv || !unq_key || !unq_cnt || !coords_bzyx) return LVQ_EINVAL;
+    if (getenv("LVQ_VOXEL_LEGACY") == nullptr) {       // slab-binned path first; the two-level-bitmap kernels below are the fallback
+        const int rc = lvq_binned_voxelize_dynamic(pts, n, c, batch_size, range_host, vsize_host, grid_host, ndim, unq_inv, pt_coords,
+                                                   unq_key, unq_cnt, coords_bzyx, counts, ws, ws_bytes, st);
+        if (rc != LVQ_EUNSUPPORTED) return rc;
+    }
     LvqArena arena(ws, ws_bytes);
     DynWs w;
     dyn_layout(arena, w, n, ks);

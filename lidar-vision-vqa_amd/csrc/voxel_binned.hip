@@ -1,0 +1,411 @@
+// csrc/voxel_binned.hip -- slab-binned voxelisation: coalesced passes + LDS-local hashing (gfx950).
+//
+// The first implementation (voxel.hip) is exact but bound by OPERATIONS, not bytes: 3 scattered memory-side
+// atomics per point (~20 G/s chip-wide) and 2-3 dependent beyond-L2 gathers per point (~10 G/s) -> 283 us for
+// 524k points where the byte roofline is ~15 us.  This file restructures the work the MI355X way:
+//
+//   pass A  (k_bin_hist / k_bin_scatter)  one counting sort of the points by SLAB = a contiguous range of 2^LOGSLAB
+//           linear keys (key = ((b*nx + cx)*ny + cy)*nz + cz, the reference's ascending torch.unique order).
+//           Histograms are built in LDS per 4096-point block (LDS atomics), only non-empty bins touch global memory,
+//           and the scatter writes (orig index, in-slab offset[, 16-byte point]) runs grouped per (block, slab).
+//   pass B  one workgroup per slab, everything in LDS: a DENSE occupancy bitmap of the slab (<= 16 KB), a popcount
+//           scan that ranks the occupied cells (= sorted-unique order inside the slab, and slabs are key-ordered, so
+//           the dynamic path's unq_key / coords / counts leave as SEQUENTIAL stores), per-voxel counters in LDS.
+//   global  only tiny scans over slabs (<= 8192 entries).
+//
+// Caps: a slab with more voxels than the LDS counters hold falls back to global atomics for that slab only.
+// Shapes the binned path does not take (key space > 2^30, C != 4 payloads, ...) use the voxel.hip kernels.
+#include "common.h"
+
+namespace vb {
+
+struct Geom {
+    float lo[3];
+    float vs[3];
+    int grid[3];
+};
+
+struct BinCfg {
+    int logslab;       // keys per slab = 1 << logslab
+    int nslabs;        // <= 8192
+    int ndim;          // 2 or 3 (dynamic); hard is always 3
+    int n_scenes;
+    int mode;          // 0: dynamic layout (col 0 = batch idx, xyz in 1..3); 1: hard layout (scene from scene_off, xyz in 0..2)
+};
+
+constexpr int MAX_SLABS = 8192;
+constexpr int BIN_BLOCK = 1024;         // threads
+constexpr int BIN_PPT = 4;              // points per thread
+
+__device__ __forceinline__ int find_scene(const int32_t *off, int n_scenes, int i) {
+    int lo = 0, hi = n_scenes;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// linear key of point i or -1; cc = cell coordinates (cx, cy, cz)
+__device__ __forceinline__ int64_t key_of(const float *__restrict__ pts, int i, int c, const Geom &g, const BinCfg &cfg,
+                                         const int32_t *__restrict__ scene_off, int cc[3]) {
+    const float *p = pts + (int64_t)i * c;
+    const float *xyz = cfg.mode == 0 ? p + 1 : p;
+    bool ok = true;
+    cc[0] = cc[1] = cc[2] = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        if (j < cfg.ndim) {
+            float d = xyz[j] - g.lo[j];
+            float q = d / g.vs[j];
+            float f = floorf(q);
+            bool in = (f >= 0.0f) && (f < (float)g.grid[j]);
+            ok = ok && in;
+            cc[j] = in ? (int)f : -1;
+        }
+    }
+    int b;
+    if (cfg.mode == 0) {
+        b = (int)p[0];
+        ok = ok && b >= 0 && b < cfg.n_scenes;
+    } else {
+        b = find_scene(scene_off, cfg.n_scenes, i);
+    }
+    if (!ok) return -1;
+    int64_t key = ((int64_t)b * g.grid[0] + cc[0]) * g.grid[1] + cc[1];
+    if (cfg.ndim == 3) key = key * g.grid[2] + cc[2];
+    return key;
+}
+
+// ---- pass A1: per-slab histogram (LDS), pt_coords / invalid markers ----
+__global__ void __launch_bounds__(BIN_BLOCK) k_bin_hist(const float *__restrict__ pts, int n, int c, Geom g, BinCfg cfg,
+                                                        const int32_t *__restrict__ scene_off, int32_t *__restrict__ ghist,
+                                                        int32_t *__restrict__ pt_coords, int32_t *__restrict__ inv_or_null) {
+    extern __shared__ int32_t lh[];
+    for (int b = threadIdx.x; b < cfg.nslabs; b += BIN_BLOCK) lh[b] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * (BIN_BLOCK * BIN_PPT);
+#pragma unroll
+    for (int u = 0; u < BIN_PPT; ++u) {
+        const int i = base + u * BIN_BLOCK + threadIdx.x;
+        if (i < n) {
+            int cc[3];
+            const int64_t key = key_of(pts, i, c, g, cfg, scene_off, cc);
+            if (pt_coords) { pt_coords[i * 3] = cc[0]; pt_coords[i * 3 + 1] = cc[1]; pt_coords[i * 3 + 2] = cc[2]; }
+            if (key >= 0) atomicAdd(&lh[(int)(key >> cfg.logslab)], 1);
+            else if (inv_or_null) inv_or_null[i] = -1;
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < cfg.nslabs; b += BIN_BLOCK)
+        if (lh[b]) atomicAdd(&ghist[b], lh[b]);
+}
+
+// ---- single-workgroup exclusive scan of <= MAX_SLABS ints: out[0..n] ; also zeroes `zero_me` ----
+__global__ void __launch_bounds__(1024) k_scan_small(const int32_t *__restrict__ in, int n, int32_t *__restrict__ out,
+                                                     int32_t *__restrict__ zero_me, int32_t *__restrict__ total_out) {
+    __shared__ int wave_tot[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int running = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n ? in[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            const int t = wave_tot[w];
+            if (w < wid) wbase += t;
+            tot += t;
+        }
+        __syncthreads();
+        if (i < n) {
+            out[i] = running + wbase + incl - v;
+            if (zero_me) zero_me[i] = 0;
+        }
+        running += tot;
+    }
+    if (threadIdx.x == 0) {
+        out[n] = running;
+        if (total_out) *total_out = running;
+    }
+}
+
+// ---- pass A3: scatter (orig idx, in-slab offset[, point]) grouped by slab ----
+__global__ void __launch_bounds__(BIN_BLOCK) k_bin_scatter(const float *__restrict__ pts, int n, int c, Geom g, BinCfg cfg,
+                                                           const int32_t *__restrict__ scene_off,
+                                                           const int32_t *__restrict__ gstart, int32_t *__restrict__ cursor,
+                                                           int32_t *__restrict__ sidx, int32_t *__restrict__ soff,
+                                                           float4 *__restrict__ spts) {
+    extern __shared__ int32_t lds[];
+    int32_t *lh = lds, *lb = lds + cfg.nslabs;
+    for (int b = threadIdx.x; b < cfg.nslabs; b += BIN_BLOCK) lh[b] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * (BIN_BLOCK * BIN_PPT);
+    int64_t keys[BIN_PPT];
+#pragma unroll
+    for (int u = 0; u < BIN_PPT; ++u) {
+        const int i = base + u * BIN_BLOCK + threadIdx.x;
+        keys[u] = -1;
+        if (i < n) {
+            int cc[3];
+            keys[u] = key_of(pts, i, c, g, cfg, scene_off, cc);
+            if (keys[u] >= 0) atomicAdd(&lh[(int)(keys[u] >> cfg.logslab)], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < cfg.nslabs; b += BIN_BLOCK) {
+        const int h = lh[b];
+        lb[b] = h ? gstart[b] + atomicAdd(&cursor[b], h) : 0;
+        lh[b] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < BIN_PPT; ++u) {
+        const int i = base + u * BIN_BLOCK + threadIdx.x;
+        if (keys[u] >= 0) {
+            const int s = (int)(keys[u] >> cfg.logslab);
+            const int pos = lb[s] + atomicAdd(&lh[s], 1);
+            sidx[pos] = i;
+            soff[pos] = (int)(keys[u] & ((1ll << cfg.logslab) - 1));
+            if (spts) spts[pos] = reinterpret_cast<const float4 *>(pts)[i];
+        }
+    }
+}
+
+constexpr int SLAB_NT = 1024;     // threads per slab workgroup (dense slabs set the tail; 256 threads were 2x slower)
+
+// ---- block-wide exclusive scan helper (blockDim.x = SLAB_NT) ----
+__device__ __forceinline__ int block_excl_scan256(int v, int *wave_tot, int &total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SLAB_NT / 64; ++w) {
+        const int t = wave_tot[w];
+        if (w < wid) wbase += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return wbase + incl - v;
+}
+
+// floor(a / d) for 0 <= a < 2^30, d >= 1: float estimate + one correction step each way
+__device__ __forceinline__ int fdiv(int a, int d, float rd) {
+    int q = (int)((float)a * rd);
+    int r = a - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+
+__device__ __forceinline__ int popc_below(uint64_t m, int bit) {
+    return __popcll(m & ((bit == 0) ? 0ull : (~0ull >> (64 - bit))));
+}
+
+// ---- dynamic pass B: occupied cells per slab ----
+__global__ void __launch_bounds__(SLAB_NT) k_dyn_slab_count(BinCfg cfg, const int32_t *__restrict__ gstart,
+                                                        const int32_t *__restrict__ soff, int32_t *__restrict__ slab_cnt) {
+    extern __shared__ unsigned long long bm[];
+    __shared__ int wave_tot[SLAB_NT / 64];
+    const int s = blockIdx.x;
+    const int p0 = gstart[s], p1 = gstart[s + 1];
+    if (p0 == p1) {
+        if (threadIdx.x == 0) slab_cnt[s] = 0;
+        return;
+    }
+    const int nw = 1 << (cfg.logslab - 6);
+    for (int w = threadIdx.x; w < nw; w += SLAB_NT) bm[w] = 0ull;
+    __syncthreads();
+    for (int p = p0 + threadIdx.x; p < p1; p += SLAB_NT) {
+        const int off = soff[p];
+        atomicOr(&bm[off >> 6], 1ull << (off & 63));
+    }
+    __syncthreads();
+    int c = 0;
+    for (int w = threadIdx.x; w < nw; w += SLAB_NT) c += __popcll(bm[w]);
+    int tot;
+    block_excl_scan256(c, wave_tot, tot);
+    if (threadIdx.x == 0) slab_cnt[s] = tot;
+}
+
+constexpr int DYN_VCAP = 4096;   // per-slab voxel counters held in LDS
+
+// ---- dynamic pass B': ranks, inverse map, sequential unique outputs ----
+__global__ void __launch_bounds__(SLAB_NT) k_dyn_slab_write(BinCfg cfg, Geom g, const int32_t *__restrict__ gstart,
+                                                        const int32_t *__restrict__ sidx, const int32_t *__restrict__ soff,
+                                                        const int32_t *__restrict__ slab_vbase, int32_t *__restrict__ unq_inv,
+                                                        int32_t *__restrict__ unq_key, int32_t *__restrict__ unq_cnt,
+                                                        int32_t *__restrict__ coords_bzyx) {
+    extern __shared__ unsigned long long smem64[];
+    __shared__ int wave_tot[SLAB_NT / 64];
+    const int s = blockIdx.x;
+    const int p0 = gstart[s], p1 = gstart[s + 1];
+    if (p0 == p1) return;
+    const int nw = 1 << (cfg.logslab - 6);
+    unsigned long long *bm = smem64;                               // [nw]
+    int32_t *wpre = reinterpret_cast<int32_t *>(smem64 + nw);      // [nw]
+    int32_t *cnt_l = wpre + nw;                                    // [DYN_VCAP]
+    const int vbase = slab_vbase[s], nvox = slab_vbase[s + 1] - vbase;
+    const bool lds_cnt = nvox <= DYN_VCAP;
+    for (int w = threadIdx.x; w < nw; w += SLAB_NT) bm[w] = 0ull;
+    for (int v = threadIdx.x; v < DYN_VCAP; v += SLAB_NT) cnt_l[v] = 0;
+    __syncthreads();
+    for (int p = p0 + threadIdx.x; p < p1; p += SLAB_NT) {
+        const int off = soff[p];
+        atomicOr(&bm[off >> 6], 1ull << (off & 63));
+    }
+    __syncthreads();
+    // exclusive popcount scan over the bitmap words (thread t owns words t*per .. t*per+per-1)
+    const int per = (nw + SLAB_NT - 1) / SLAB_NT;
+    int c = 0;
+    for (int j = 0; j < per; ++j) {
+        const int w = threadIdx.x * per + j;
+        if (w < nw) c += __popcll(bm[w]);
+    }
+    int tot;
+    int ex = block_excl_scan256(c, wave_tot, tot);
+    for (int j = 0; j < per; ++j) {
+        const int w = threadIdx.x * per + j;
+        if (w < nw) { wpre[w] = ex; ex += __popcll(bm[w]); }
+    }
+    __syncthreads();
+    // per point: rank of its voxel, inverse map, count
+    for (int p = p0 + threadIdx.x; p < p1; p += SLAB_NT) {
+        const int off = soff[p];
+        const int lr = wpre[off >> 6] + popc_below(bm[off >> 6], off & 63);
+        unq_inv[sidx[p]] = vbase + lr;
+        if (lds_cnt) atomicAdd(&cnt_l[lr], 1);
+        else atomicAdd(&unq_cnt[vbase + lr], 1);          // oversized slab: counters in global memory (pre-zeroed)
+    }
+    __syncthreads();
+    // unique outputs in ascending key order: sequential stores
+    const int64_t key0 = (int64_t)s << cfg.logslab;
+    const float rx = 1.0f / (float)g.grid[0], ry = 1.0f / (float)g.grid[1], rz = 1.0f / (float)g.grid[2];
+    for (int j = 0; j < per; ++j) {
+        const int w = threadIdx.x * per + j;
+        if (w >= nw) break;
+        unsigned long long bits = bm[w];
+        int lr = wpre[w];
+        while (bits) {
+            const int bit = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const int key = (int)(key0 + w * 64 + bit);
+            const int v = vbase + lr;
+            unq_key[v] = key;
+            if (lds_cnt) unq_cnt[v] = cnt_l[lr];
+            // key -> (b, cx, cy, cz) with float-reciprocal division (exact for key < 2^30 after the fix-up step)
+            int b, cx, cy, cz = 0, t = key;
+            if (cfg.ndim == 3) { const int q = fdiv(t, g.grid[2], rz); cz = t - q * g.grid[2]; t = q; }
+            { const int q = fdiv(t, g.grid[1], ry); cy = t - q * g.grid[1]; t = q; }
+            { const int q = fdiv(t, g.grid[0], rx); cx = t - q * g.grid[0]; b = q; }
+            reinterpret_cast<int4 *>(coords_bzyx)[v] = make_int4(b, cz, cy, cx);
+            ++lr;
+        }
+    }
+}
+
+// oversized slabs use global counters: zero the count array first (only when some slab may exceed the LDS cap)
+__global__ void k_zero_i32(int32_t *p, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = 0;
+}
+
+// slab size: average ~256-512 points per slab, dense bitmap <= 16 KB (logslab <= 17), at most MAX_SLABS slabs
+static bool choose_cfg(int64_t keyspace, int64_t n, BinCfg &cfg) {
+    if (keyspace <= 0 || keyspace > (1ll << 30)) return false;
+    int64_t want = n / 384 + 1;
+    if (want > MAX_SLABS) want = MAX_SLABS;
+    int ls = 10;
+    while (ls < 17 && ((keyspace + (1ll << ls) - 1) >> ls) > want) ++ls;
+    while (((keyspace + (1ll << ls) - 1) >> ls) > MAX_SLABS) {
+        if (ls >= 17) return false;
+        ++ls;
+    }
+    cfg.logslab = ls;
+    cfg.nslabs = (int)((keyspace + (1ll << ls) - 1) >> ls);
+    return true;
+}
+
+struct DynBinWs {
+    int32_t *ghist, *gstart, *cursor, *slab_cnt, *slab_vbase, *sidx, *soff;
+};
+
+template <typename A> void dyn_layout(A &a, DynBinWs &w, int64_t n) {
+    w.ghist = a.template take<int32_t>(MAX_SLABS + 1);
+    w.gstart = a.template take<int32_t>(MAX_SLABS + 2);
+    w.cursor = a.template take<int32_t>(MAX_SLABS + 1);
+    w.slab_cnt = a.template take<int32_t>(MAX_SLABS + 1);
+    w.slab_vbase = a.template take<int32_t>(MAX_SLABS + 2);
+    w.sidx = a.template take<int32_t>(n + 1);
+    w.soff = a.template take<int32_t>(n + 1);
+}
+
+struct SizerAdapter {
+    LvqSizer s;
+    template <typename T> T *take(size_t n) { s.template take<T>(n); return nullptr; }
+};
+
+}  // namespace vb
+
+// -------------------------------------------------------------------------------------------------
+// entry points used by voxel.hip's lvq_voxelize_dynamic (returns LVQ_EUNSUPPORTED when the binned path does not apply)
+// -------------------------------------------------------------------------------------------------
+size_t lvq_binned_dynamic_workspace_bytes(int64_t n) {
+    vb::SizerAdapter a;
+    vb::DynBinWs w;
+    vb::dyn_layout(a, w, n);
+    return a.s.total();
+}
+
+int lvq_binned_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_size, const float *range_host,
+                                const float *vsize_host, const int32_t *grid_host, int ndim, int32_t *unq_inv, int32_t *pt_coords,
+                                int32_t *unq_key, int32_t *unq_cnt, int32_t *coords_bzyx, int32_t *counts, void *ws, size_t ws_bytes,
+                                hipStream_t st) {
+    using namespace vb;
+    int64_t keyspace = (int64_t)batch_size * grid_host[0] * grid_host[1];
+    if (ndim == 3) keyspace *= grid_host[2];
+    BinCfg cfg;
+    if (!choose_cfg(keyspace, n, cfg)) return LVQ_EUNSUPPORTED;
+    cfg.ndim = ndim; cfg.n_scenes = batch_size; cfg.mode = 0;
+    LvqArena arena(ws, ws_bytes);
+    DynBinWs w;
+    dyn_layout(arena, w, n);
+    if (!arena.ok) return LVQ_EWORKSPACE;
+    Geom g;
+    for (int j = 0; j < 3; ++j) { g.lo[j] = range_host[j]; g.vs[j] = vsize_host[j]; g.grid[j] = grid_host[j]; }
+    const unsigned nb = (unsigned)lvq_cdiv(n, BIN_BLOCK * BIN_PPT);
+    const int64_t cap = n < keyspace ? n : keyspace;
+    hipMemsetAsync(w.ghist, 0, sizeof(int32_t) * (cfg.nslabs + 1), st);
+    // a slab can only exceed the LDS counter cap if it can hold that many cells AND there are that many points
+    const bool may_overflow = (1 << cfg.logslab) > DYN_VCAP && n > DYN_VCAP;
+    if (may_overflow) hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)(lvq_cdiv(cap, 256) < 1024 ? lvq_cdiv(cap, 256) : 1024)), dim3(256), 0, st, unq_cnt, cap);
+    hipLaunchKernelGGL(k_bin_hist, dim3(nb), dim3(BIN_BLOCK), sizeof(int32_t) * cfg.nslabs, st, pts, (int)n, c, g, cfg,
+                       (const int32_t *)nullptr, w.ghist, pt_coords, unq_inv);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, w.ghist, cfg.nslabs, w.gstart, w.cursor, &counts[1]);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(BIN_BLOCK), 2 * sizeof(int32_t) * cfg.nslabs, st, pts, (int)n, c, g, cfg,
+                       (const int32_t *)nullptr, w.gstart, w.cursor, w.sidx, w.soff, (float4 *)nullptr);
+    const int nw = 1 << (cfg.logslab - 6);
+    hipLaunchKernelGGL(k_dyn_slab_count, dim3(cfg.nslabs), dim3(SLAB_NT), sizeof(unsigned long long) * nw, st, cfg, w.gstart, w.soff,
+                       w.slab_cnt);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, w.slab_cnt, cfg.nslabs, w.slab_vbase, (int32_t *)nullptr, &counts[0]);
+    const size_t lds = sizeof(unsigned long long) * nw + sizeof(int32_t) * nw + sizeof(int32_t) * DYN_VCAP;
+    hipLaunchKernelGGL(k_dyn_slab_write, dim3(cfg.nslabs), dim3(SLAB_NT), lds, st, cfg, g, w.gstart, w.sidx, w.soff, w.slab_vbase, unq_inv,
+                       unq_key, unq_cnt, coords_bzyx);
+    return lvq_launch_status();
+}
