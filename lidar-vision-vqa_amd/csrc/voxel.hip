@@ -31,6 +31,12 @@ int lvq_binned_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_si
                                 int32_t *unq_key, int32_t *unq_cnt, int32_t *coords_bzyx, int32_t *counts, void *ws, size_t ws_bytes,
                                 hipStream_t st);
 
+size_t lvq_binned_hard_workspace_bytes(int64_t n, int n_scenes);
+int lvq_binned_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n, int n_scenes, int c, const float *range_host,
+                             const float *vsize_host, const int32_t *grid_host, int max_pts, int max_voxels, float *voxels,
+                             int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes,
+                             hipStream_t st);
+
 namespace {
 
 struct Geom {
@@ -554,7 +560,8 @@ extern "C" size_t lvq_voxelize_hard_workspace_bytes(int64_t n_points, int n_scen
     SizerAdapter a;
     HardWs w;
     hard_layout(a, w, n_points, n_scenes);
-    return a.s.total();
+    const size_t binned = lvq_binned_hard_workspace_bytes(n_points, n_scenes);
+    return a.s.total() > binned ? a.s.total() : binned;
 }
 
 extern "C" int lvq_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n_points, int n_scenes, int c,
@@ -575,6 +582,11 @@ extern "C" int lvq_voxelize_hard(const float *pts, const int32_t *scene_off, int
     }
     int64_t need = n_points < (int64_t)n_scenes * max_voxels ? n_points : (int64_t)n_scenes * max_voxels;
     if (voxel_capacity < need || !pts || !voxels || !coords_bzyx || !num_pts) return LVQ_EINVAL;
+    if (!break_on_cap && getenv("LVQ_VOXEL_LEGACY") == nullptr) {   // slab-binned path; the hash kernels below are the fallback
+        const int rc = lvq_binned_voxelize_hard(pts, scene_off, n_points, n_scenes, c, range_host, vsize_host, grid_host, max_pts,
+                                                max_voxels, voxels, coords_bzyx, num_pts, scene_voxel_off, ws, ws_bytes, st);
+        if (rc != LVQ_EUNSUPPORTED) return rc;
+    }
     LvqArena arena(ws, ws_bytes);
     HardWs w;
     hard_layout(arena, w, n_points, n_scenes);

@@ -361,6 +361,251 @@ struct SizerAdapter {
     template <typename T> T *take(size_t n) { s.template take<T>(n); return nullptr; }
 };
 
+// =================================================================================================================
+// hard voxeliser on the same binning pass
+// =================================================================================================================
+constexpr int HARD_VCAP = 4096;    // voxels of a slab with LDS-resident per-voxel state
+constexpr int HARD_PCAP = 8192;    // points of a slab with an LDS-resident bucket array
+
+struct HardBinWs {
+    int32_t *ghist, *gstart, *cursor;           // [MAX_SLABS+..]
+    int32_t *sidx, *soff;                       // [n] sorted by slab
+    float4 *spts;                               // [n]
+    int32_t *pfirst, *pslot, *pcnt;             // [n] per sorted position: first point index of its voxel, slot, (first point) count
+    uint8_t *fbytes;                            // [n] 1 = "first point of its cell" (by ORIGINAL index)
+    uint64_t *fmask;                            // [nwords+1]
+    int32_t *wcnt, *wpre;                       // [nwords+2]
+    int32_t *sfr;                               // [n_scenes+1]
+    int32_t *g_first, *g_cnt, *g_vstart, *g_fill, *g_bucket;   // [n] global stand-ins for oversized slabs
+};
+
+template <typename A> void hard_layout(A &a, HardBinWs &w, int64_t n, int n_scenes) {
+    const int64_t nwords = (n + 63) / 64;
+    w.ghist = a.template take<int32_t>(MAX_SLABS + 1);
+    w.gstart = a.template take<int32_t>(MAX_SLABS + 2);
+    w.cursor = a.template take<int32_t>(MAX_SLABS + 1);
+    w.sidx = a.template take<int32_t>(n + 1);
+    w.soff = a.template take<int32_t>(n + 1);
+    w.spts = a.template take<float4>(n + 1);
+    w.pfirst = a.template take<int32_t>(n + 1);
+    w.pslot = a.template take<int32_t>(n + 1);
+    w.pcnt = a.template take<int32_t>(n + 1);
+    w.fbytes = a.template take<uint8_t>(n + 64);
+    w.fmask = a.template take<uint64_t>(nwords + 2);
+    w.wcnt = a.template take<int32_t>(nwords + 2);
+    w.wpre = a.template take<int32_t>(nwords + 3);
+    w.sfr = a.template take<int32_t>(n_scenes + 2);
+    w.g_first = a.template take<int32_t>(n + 1);
+    w.g_cnt = a.template take<int32_t>(n + 1);
+    w.g_vstart = a.template take<int32_t>(n + 1);
+    w.g_fill = a.template take<int32_t>(n + 1);
+    w.g_bucket = a.template take<int32_t>(n + 1);
+}
+
+constexpr int SMALL_PCAP = 256;   // slabs up to this many points take the brute-force LDS kernel
+
+// ---- hard pass B, ordinary slabs: every point scans the slab's (cell, index) pairs in LDS once ----
+// slot = #points of the same cell with a smaller index, first = smallest index of the cell, count = size of the cell.
+// No atomics, no scans, two barriers; O(n_s^2) LDS broadcast reads with n_s ~ a few hundred.
+__global__ void __launch_bounds__(256) k_hard_slab_small(BinCfg cfg, HardBinWs w) {
+    __shared__ __attribute__((aligned(16))) int2 pr[SMALL_PCAP + 8];
+    const int s = blockIdx.x;
+    const int p0 = w.gstart[s], np = w.gstart[s + 1] - p0;
+    if (np == 0 || np > SMALL_PCAP) return;
+    const int np8 = (np + 7) & ~7;
+    for (int j = threadIdx.x; j < np8; j += 256)
+        pr[j] = j < np ? make_int2(w.soff[p0 + j], w.sidx[p0 + j]) : make_int2(-1, 0x7fffffff);   // padding never matches
+    __syncthreads();
+    for (int j = threadIdx.x; j < np; j += 256) {
+        const int2 me = pr[j];
+        int r = 0, cnt = 0, f = 0x7fffffff;
+        for (int k = 0; k < np8; k += 8) {               // 4 x 16-byte broadcast reads in flight per step
+            int4 q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const int4 *>(&pr[k + 2 * u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool s0 = q[u].x == me.x, s1 = q[u].z == me.x;
+                r += (s0 && q[u].y < me.y) + (s1 && q[u].w < me.y);
+                cnt += s0 + s1;
+                f = s0 ? min(f, q[u].y) : f;
+                f = s1 ? min(f, q[u].w) : f;
+            }
+        }
+        w.pfirst[p0 + j] = f;
+        w.pslot[p0 + j] = r;
+        if (me.y == f) {
+            w.pcnt[p0 + j] = cnt;
+            w.fbytes[f] = 1;
+        }
+    }
+}
+
+// ---- hard pass B, dense slabs (> SMALL_PCAP points): one workgroup per slab ----
+// LDS: bitmap | word prefix | first[VCAP] cnt[VCAP] vstart[VCAP] fill[VCAP] | bucket[PCAP].  A slab that exceeds a cap
+// uses the same code on global stand-in arrays (generic pointers), bounded but slow -- only pathological densities.
+__global__ void __launch_bounds__(SLAB_NT) k_hard_slab(BinCfg cfg, int T, HardBinWs w) {
+    extern __shared__ unsigned long long smem64[];
+    __shared__ int wave_tot[SLAB_NT / 64];
+    const int s = blockIdx.x;
+    const int p0 = w.gstart[s], p1 = w.gstart[s + 1];
+    const int np = p1 - p0;
+    if (np <= SMALL_PCAP) return;                       // ordinary slabs were done by k_hard_slab_small
+    const int nw = 1 << (cfg.logslab - 6);
+    unsigned long long *bm = smem64;
+    int32_t *wpre = reinterpret_cast<int32_t *>(smem64 + nw);
+    int32_t *l_first = wpre + nw, *l_cnt = l_first + HARD_VCAP, *l_vstart = l_cnt + HARD_VCAP, *l_fill = l_vstart + HARD_VCAP;
+    int32_t *l_bucket = l_fill + HARD_VCAP;
+    const int tid = threadIdx.x;
+
+    for (int x = tid; x < nw; x += SLAB_NT) bm[x] = 0ull;
+    __syncthreads();
+    for (int p = p0 + tid; p < p1; p += SLAB_NT) {
+        const int off = w.soff[p];
+        atomicOr(&bm[off >> 6], 1ull << (off & 63));
+    }
+    __syncthreads();
+    const int per = (nw + SLAB_NT - 1) / SLAB_NT;
+    int c = 0;
+    for (int j = 0; j < per; ++j) {
+        const int x = tid * per + j;
+        if (x < nw) c += __popcll(bm[x]);
+    }
+    int nvox;
+    int ex = block_excl_scan256(c, wave_tot, nvox);
+    for (int j = 0; j < per; ++j) {
+        const int x = tid * per + j;
+        if (x < nw) { wpre[x] = ex; ex += __popcll(bm[x]); }
+    }
+    // per-voxel state: LDS when it fits, else this slab's range of the global stand-ins (generic pointers)
+    const bool vfit = nvox <= HARD_VCAP, pfit = np <= HARD_PCAP;
+    int32_t *first = vfit ? l_first : w.g_first + p0;
+    int32_t *cnt = vfit ? l_cnt : w.g_cnt + p0;
+    int32_t *vstart = vfit ? l_vstart : w.g_vstart + p0;
+    int32_t *fill = vfit ? l_fill : w.g_fill + p0;
+    int32_t *bucket = pfit ? l_bucket : w.g_bucket + p0;
+    for (int v = tid; v < nvox; v += SLAB_NT) { first[v] = 0x7fffffff; cnt[v] = 0; fill[v] = 0; }
+    const bool glob = !(vfit && pfit);       // global stand-ins need device-scope visibility between the phases
+    if (glob) __threadfence();
+    __syncthreads();
+    // first index and count per voxel
+    for (int p = p0 + tid; p < p1; p += SLAB_NT) {
+        const int off = w.soff[p];
+        const int lr = wpre[off >> 6] + popc_below(bm[off >> 6], off & 63);
+        atomicMin(&first[lr], w.sidx[p]);
+        atomicAdd(&cnt[lr], 1);
+    }
+    if (glob) __threadfence();
+    __syncthreads();
+    // bucket offsets: exclusive scan of the counts (chunks of SLAB_NT voxels)
+    int running = 0;
+    for (int base = 0; base < nvox; base += SLAB_NT) {
+        const int v = base + tid;
+        const int x = v < nvox ? cnt[v] : 0;
+        int tot;
+        const int e2 = block_excl_scan256(x, wave_tot, tot);
+        if (v < nvox) vstart[v] = running + e2;
+        running += tot;
+    }
+    if (glob) __threadfence();
+    __syncthreads();
+    for (int p = p0 + tid; p < p1; p += SLAB_NT) {
+        const int off = w.soff[p];
+        const int lr = wpre[off >> 6] + popc_below(bm[off >> 6], off & 63);
+        bucket[vstart[lr] + atomicAdd(&fill[lr], 1)] = w.sidx[p];
+    }
+    if (glob) __threadfence();
+    __syncthreads();
+    // slot of every point = number of smaller indices in its voxel (stop at T unless it is the first point)
+    for (int p = p0 + tid; p < p1; p += SLAB_NT) {
+        const int off = w.soff[p], idx = w.sidx[p];
+        const int lr = wpre[off >> 6] + popc_below(bm[off >> 6], off & 63);
+        const int f = first[lr], n_in = cnt[lr];
+        int r = 0;
+        if (n_in > 1 && idx != f) {
+            const int32_t *b = bucket + vstart[lr];
+            for (int j = 0; j < n_in; ++j) {
+                r += (b[j] < idx);
+                if (r >= T) break;
+            }
+        }
+        w.pfirst[p] = f;
+        w.pslot[p] = r;
+        if (idx == f) {
+            w.pcnt[p] = n_in;
+            w.fbytes[f] = 1;         // first-appearance flag by ORIGINAL index (plain byte store, no atomic)
+        }
+    }
+}
+
+// first-flag bytes -> 64-bit mask words + per-word counts
+__global__ void __launch_bounds__(256) k_flags_to_words(const uint8_t *__restrict__ fbytes, int n, uint64_t *__restrict__ fmask,
+                                                        int32_t *__restrict__ wcnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool f = i < n && fbytes[i];
+    const unsigned long long m = __ballot(f);
+    if ((threadIdx.x & 63) == 0 && i < n) { fmask[i >> 6] = m; wcnt[i >> 6] = __popcll(m); }
+}
+
+__device__ __forceinline__ int first_rank(const HardBinWs &w, int i) {
+    return w.wpre[i >> 6] + popc_below(w.fmask[i >> 6], i & 63);
+}
+
+__global__ void k_hard_scene_offsets2(const int32_t *__restrict__ scene_off, int n, int n_scenes, int max_voxels, HardBinWs w,
+                                      int32_t *__restrict__ scene_voxel_off) {
+    const int nwords = (n + 63) / 64;
+    for (int s = threadIdx.x; s <= n_scenes; s += blockDim.x) {
+        const int i = scene_off[s];
+        w.sfr[s] = (i >> 6) < nwords ? first_rank(w, i) : w.wpre[nwords];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int s = 0; s < n_scenes; ++s) {
+            scene_voxel_off[s] = acc;
+            const int tot = w.sfr[s + 1] - w.sfr[s];
+            acc += tot < max_voxels ? tot : max_voxels;
+        }
+        scene_voxel_off[n_scenes] = acc;
+    }
+}
+
+// ---- hard pass C: placement, one thread per sorted position (coalesced reads, 16-byte row stores) ----
+__global__ void __launch_bounds__(256) k_hard_place(int n_sorted, BinCfg cfg, Geom g, int T, int max_voxels,
+                                                    const int32_t *__restrict__ scene_off, HardBinWs w,
+                                                    const int32_t *__restrict__ scene_voxel_off, float *__restrict__ voxels,
+                                                    int32_t *__restrict__ coords_bzyx, int32_t *__restrict__ num_pts) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_sorted || p >= w.gstart[cfg.nslabs]) return;     // only the binned (in-range) points have sorted positions
+    const int f = w.pfirst[p], r = w.pslot[p], idx = w.sidx[p];
+    const int s = find_scene(scene_off, cfg.n_scenes, f);
+    const int rank = first_rank(w, f) - w.sfr[s];
+    if (rank >= max_voxels) return;                       // voxel never created (`continue` semantics)
+    const int v = scene_voxel_off[s] + rank;
+    float4 *row = reinterpret_cast<float4 *>(voxels) + (int64_t)v * T;
+    if (r < T) row[r] = w.spts[p];
+    if (idx == f) {
+        const int cntv = w.pcnt[p];
+        const int npv = cntv < T ? cntv : T;
+        num_pts[v] = npv;
+        for (int k = npv; k < T; ++k) row[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // cell coordinates from the key: key = ((b*nx + cx)*ny + cy)*nz + cz
+        // (slab id recovered from the sorted position via binary search over gstart)
+        int lo = 0, hi = cfg.nslabs;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (w.gstart[mid] <= p) lo = mid; else hi = mid;
+        }
+        const int64_t key = ((int64_t)lo << cfg.logslab) + w.soff[p];
+        const float rx = 1.0f / (float)g.grid[0], ry = 1.0f / (float)g.grid[1], rz = 1.0f / (float)g.grid[2];
+        int t = (int)key;
+        int q = fdiv(t, g.grid[2], rz); const int cz = t - q * g.grid[2]; t = q;
+        q = fdiv(t, g.grid[1], ry); const int cy = t - q * g.grid[1]; t = q;
+        q = fdiv(t, g.grid[0], rx); const int cx = t - q * g.grid[0];
+        reinterpret_cast<int4 *>(coords_bzyx)[v] = make_int4(s, cz, cy, cx);
+    }
+}
+
 }  // namespace vb
 
 // -------------------------------------------------------------------------------------------------
@@ -407,5 +652,57 @@ int lvq_binned_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_si
     const size_t lds = sizeof(unsigned long long) * nw + sizeof(int32_t) * nw + sizeof(int32_t) * DYN_VCAP;
     hipLaunchKernelGGL(k_dyn_slab_write, dim3(cfg.nslabs), dim3(SLAB_NT), lds, st, cfg, g, w.gstart, w.sidx, w.soff, w.slab_vbase, unq_inv,
                        unq_key, unq_cnt, coords_bzyx);
+    return lvq_launch_status();
+}
+
+size_t lvq_binned_hard_workspace_bytes(int64_t n, int n_scenes) {
+    vb::SizerAdapter a;
+    vb::HardBinWs w;
+    vb::hard_layout(a, w, n, n_scenes);
+    return a.s.total();
+}
+
+// `continue` cap semantics, C == 4 payloads, key space <= 2^30; anything else -> LVQ_EUNSUPPORTED (legacy kernels)
+int lvq_binned_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n, int n_scenes, int c, const float *range_host,
+                             const float *vsize_host, const int32_t *grid_host, int max_pts, int max_voxels, float *voxels,
+                             int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes,
+                             hipStream_t st) {
+    using namespace vb;
+    if (c != 4 || (((uintptr_t)pts | (uintptr_t)voxels) & 15)) return LVQ_EUNSUPPORTED;
+    const int64_t keyspace = (int64_t)n_scenes * grid_host[0] * grid_host[1] * grid_host[2];
+    BinCfg cfg;
+    if (!choose_cfg(keyspace, n, cfg)) return LVQ_EUNSUPPORTED;
+    cfg.ndim = 3; cfg.n_scenes = n_scenes; cfg.mode = 1;
+    LvqArena arena(ws, ws_bytes);
+    HardBinWs w;
+    hard_layout(arena, w, n, n_scenes);
+    if (!arena.ok) return LVQ_EWORKSPACE;
+    Geom g;
+    for (int j = 0; j < 3; ++j) { g.lo[j] = range_host[j]; g.vs[j] = vsize_host[j]; g.grid[j] = grid_host[j]; }
+    const unsigned nb = (unsigned)lvq_cdiv(n, BIN_BLOCK * BIN_PPT);
+    const int64_t nwords = (n + 63) / 64;
+    hipMemsetAsync(w.ghist, 0, sizeof(int32_t) * (cfg.nslabs + 1), st);
+    hipMemsetAsync(w.fbytes, 0, (size_t)n + 64, st);
+    hipLaunchKernelGGL(k_bin_hist, dim3(nb), dim3(BIN_BLOCK), sizeof(int32_t) * cfg.nslabs, st, pts, (int)n, c, g, cfg, scene_off, w.ghist,
+                       (int32_t *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, w.ghist, cfg.nslabs, w.gstart, w.cursor, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(BIN_BLOCK), 2 * sizeof(int32_t) * cfg.nslabs, st, pts, (int)n, c, g, cfg, scene_off,
+                       w.gstart, w.cursor, w.sidx, w.soff, w.spts);
+    const int nw = 1 << (cfg.logslab - 6);
+    const size_t lds = sizeof(unsigned long long) * nw + sizeof(int32_t) * nw + sizeof(int32_t) * (4 * HARD_VCAP + HARD_PCAP);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void *)k_hard_slab, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        attr = true;
+    }
+    hipLaunchKernelGGL(k_hard_slab_small, dim3(cfg.nslabs), dim3(256), 0, st, cfg, w);
+    if (n > SMALL_PCAP) hipLaunchKernelGGL(k_hard_slab, dim3(cfg.nslabs), dim3(SLAB_NT), lds, st, cfg, max_pts, w);
+    hipLaunchKernelGGL(k_flags_to_words, dim3((unsigned)lvq_cdiv(nwords * 64, 256)), dim3(256), 0, st, w.fbytes, (int)(nwords * 64), w.fmask,
+                       w.wcnt);
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, w.wcnt, (int)nwords, w.wpre, (int32_t *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_hard_scene_offsets2, dim3(1), dim3(256), 0, st, scene_off, (int)n, n_scenes, max_voxels, w, scene_voxel_off);
+    // the number of binned (valid) points is only known on the device (gstart[nslabs]); launch over n and let extra threads exit
+    hipLaunchKernelGGL(k_hard_place, dim3((unsigned)lvq_cdiv(n, 256)), dim3(256), 0, st, (int)n, cfg, g, max_pts, max_voxels, scene_off, w,
+                       scene_voxel_off, voxels, coords_bzyx, num_pts);
     return lvq_launch_status();
 }
