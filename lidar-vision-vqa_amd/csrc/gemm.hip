@@ -91,10 +91,14 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_bf16(GemmArgs g) {
     const int n_it = nk * g.nseg;
 
     uint4 ra[LA], rb[LB];
-    auto gload = [&](int it) {
+    // segment bases as SGPR-resident deltas: an indexed read of the kernarg array inside the K loop is an s_load (a pending
+    // scalar load forces every LDS wait to lgkmcnt(0)), and a select chain over the three loaded pointers gets turned back
+    // into a private-memory lookup table by the optimiser
+    const int64_t dA1 = g.a[1] - g.a[0], dA2 = g.a[2] - g.a[0], dW1 = g.w[1] - g.w[0], dW2 = g.w[2] - g.w[0];
+    auto gload = [&](int it) __attribute__((always_inline)) {
         const int seg = it / nk, k0 = (it - seg * nk) * BK;
-        const uint16_t *A = g.a[seg] + z * g.a_bs;
-        const uint16_t *W = g.w[seg] + z * g.w_bs;
+        const uint16_t *A = (g.a[0] + (seg == 0 ? (int64_t)0 : seg == 1 ? dA1 : dA2)) + z * g.a_bs;
+        const uint16_t *W = (g.w[0] + (seg == 0 ? (int64_t)0 : seg == 1 ? dW1 : dW2)) + z * g.w_bs;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
             const int q = tid + NT * i, row = q >> 3, kk = k0 + (q & 7) * 8;
@@ -108,7 +112,7 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_bf16(GemmArgs g) {
             rb[i] = (gn < g.N && kk < g.K) ? *reinterpret_cast<const uint4 *>(W + (int64_t)gn * g.ldw + kk) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
         uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
@@ -128,10 +132,14 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_bf16(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto stage_dma = [&](int it, int buf) {
-        const int seg = it / nk, k0 = (it - seg * nk) * BK;
-        const uint16_t *A = g.a[seg] + z * g.a_bs;
-        const uint16_t *W = g.w[seg] + z * g.w_bs;
+    // tiles are staged strictly in order, so (segment, k0) just advance (no division in the loop)
+    int d_seg = 0, d_k0 = 0;
+    auto stage_dma = [&](int /*it*/, int buf) __attribute__((always_inline)) {
+        const int seg = d_seg, k0 = d_k0;
+        d_k0 += BK;
+        if (d_k0 >= nk * BK) { d_k0 = 0; ++d_seg; }
+        const uint16_t *A = (g.a[0] + (seg == 0 ? (int64_t)0 : seg == 1 ? dA1 : dA2)) + z * g.a_bs;
+        const uint16_t *W = (g.w[0] + (seg == 0 ? (int64_t)0 : seg == 1 ? dW1 : dW2)) + z * g.w_bs;
         uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
         const int r8 = lane >> 3, pch = lane & 7;
 #pragma unroll
@@ -154,7 +162,7 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_bf16(GemmArgs g) {
         }
     };
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -180,25 +188,86 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_bf16(GemmArgs g) {
     };
 
     if (NSTAGE == 3) {
-        // pieces per wave per stage: BM/(8*NW) + BN/(8*NW) global_load_lds instructions
+        // Software-pipelined ring: the fragments of K-half ks+1 are read from LDS while the MFMAs of K-half ks run, and
+        // the counted wait + barrier sits in the MIDDLE of the tile, so the first fragments of tile it+1 are prefetched
+        // under the second MFMA cluster of tile it (the 2-barrier form left the matrix pipe idle during every read burst).
+        constexpr int NLD = BM / (8 * NW) + BN / (8 * NW);       // global_load_lds per wave per stage
+        auto read_frags = [&](int buf, int ks, bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) {
+            const uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * WTM + i * 16 + (lane & 15);
+                const int ch = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
+                af[i] = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + ch * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn * (BN / 2) + j * 16 + (lane & 15);
+                const int ch = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
+                bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + ch * 16);
+            }
+        };
+        auto mma = [&](bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        };
         stage_dma(0, 0);
         if (n_it > 1) {
             stage_dma(1, 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / (8 * NW) + BN / (8 * NW)) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
+        bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+        read_frags(0, 0, a0, b0);
+        // drain scalar loads before the loop (builtin, so the waitcnt pass sees it): a pending s_load in the pre-header state
+        // would make every LDS wait inside the loop lgkmcnt(0) instead of a counted one
+        __builtin_amdgcn_s_waitcnt(0xc07f);
         int buf = 0;
-        for (int it = 0; it < n_it; ++it) {
+        // the last two tiles are peeled so the steady-state body is branch-free (the waitcnt pass merges states at every
+        // join: with a conditional wait it falls back to lgkmcnt(0) after the prefetch reads and the overlap is lost)
+        for (int it = 0; it + 2 < n_it; ++it) {
             int nb = buf + 2; nb = nb >= 3 ? nb - 3 : nb;
-            if (it + 2 < n_it) stage_dma(it + 2, nb);          // its buffer was last read in iteration it-1 (barrier since)
-            compute(buf);
-            if (it + 2 < n_it) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BM / (8 * NW) + BN / (8 * NW)) : "memory");   // tile it+1 landed, it+2 in flight
-            else               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int nx = buf == 2 ? 0 : buf + 1;
+            stage_dma(it + 2, nb);                             // slot last read in iteration it-1 (mid-tile barrier since)
+            read_frags(buf, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            // tile it+1 landed (tile it+2 stays in flight); every LDS read of tile `it` has completed before the barrier.
+            // Builtin form so the compiler's waitcnt pass knows a1/b1 are complete (gfx9 encoding: vmcnt[3:0] | expcnt<<4 |
+            // lgkmcnt<<8 | vmcnt[5:4]<<14)
+            __builtin_amdgcn_s_waitcnt((NLD & 15) | 0x70 | ((NLD >> 4) << 14));
             __builtin_amdgcn_s_barrier();
-            buf = buf + 1 >= 3 ? 0 : buf + 1;
+            read_frags(nx, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);                // a0/b0 landed under the 16 MFMAs above: free, and it keeps the
+            buf = nx;                                          // compiler from placing a full lgkmcnt(0) after the NEXT reads
         }
+        if (n_it > 1) {                                        // tile n_it-2: nothing left to stage, drain the DMA queue
+            const int nx = buf == 2 ? 0 : buf + 1;
+            read_frags(buf, 1, a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            __builtin_amdgcn_s_barrier();
+            read_frags(nx, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            buf = nx;
+        }
+        read_frags(buf, 1, a1, b1);
+        mma(a0, b0);
+        mma(a1, b1);
+        __builtin_amdgcn_s_barrier();      // epilogue reuses the ring as its transpose slab
     } else {
         if (GLDS) {
             stage_dma(0, 0);
@@ -346,10 +415,15 @@ __global__ void __launch_bounds__(512) k_gemm_persist(GemmArgs g) {
     const int G = gridDim.x;
     const int gx = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);   // position inside a round (G % 8 == 0)
 
-    auto stage_dma = [&](int64_t m0, int n0, int it, int buf) {
-        const int seg = it / nk, k0 = (it - seg * nk) * BK;
-        const uint16_t *A = g.a[seg] + z * g.a_bs;
-        const uint16_t *W = g.w[seg] + z * g.w_bs;
+    // segment bases as SGPR deltas + in-order (segment, k0) state: see k_gemm_bf16
+    const int64_t dA1 = g.a[1] - g.a[0], dA2 = g.a[2] - g.a[0], dW1 = g.w[1] - g.w[0], dW2 = g.w[2] - g.w[0];
+    int d_seg = 0, d_k0 = 0;
+    auto stage_dma = [&](int64_t m0, int n0, int buf) __attribute__((always_inline)) {
+        const int seg = d_seg, k0 = d_k0;
+        d_k0 += BK;
+        if (d_k0 >= nk * BK) { d_k0 = 0; ++d_seg; }
+        const uint16_t *A = (g.a[0] + (seg == 0 ? (int64_t)0 : seg == 1 ? dA1 : dA2)) + z * g.a_bs;
+        const uint16_t *W = (g.w[0] + (seg == 0 ? (int64_t)0 : seg == 1 ? dW1 : dW2)) + z * g.w_bs;
         uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
         const int r8 = lane >> 3, pch = lane & 7;
 #pragma unroll
@@ -371,12 +445,27 @@ __global__ void __launch_bounds__(512) k_gemm_persist(GemmArgs g) {
                                              (__attribute__((address_space(3))) void *)(sb + piece * 1024), 16, 0, 0);
         }
     };
-    auto tile_of = [&](int round, int64_t &m0, int &n0) -> bool {
+    auto tile_of = [&](int round, int64_t &m0, int &n0) __attribute__((always_inline)) -> bool {
         const int64_t t = (int64_t)round * G + gx;
         if (t >= g.ntiles) return false;
         m0 = (t / g.ntx) * BM;
         n0 = (int)(t % g.ntx) * BN;
         return true;
+    };
+    auto read_frags = [&](int buf, int ks, bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) __attribute__((always_inline)) {
+        const uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = wm * WTM + i * 16 + (lane & 15);
+            const int ch = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
+            af[i] = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + ch * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wn * (BN / 2) + j * 16 + (lane & 15);
+            const int ch = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
+            bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + ch * 16);
+        }
     };
 
     int64_t m0 = 0, nm0 = 0;
@@ -384,8 +473,8 @@ __global__ void __launch_bounds__(512) k_gemm_persist(GemmArgs g) {
     int round = 0, buf = 0;
     bool have = tile_of(0, m0, n0);
     if (have) {
-        stage_dma(m0, n0, 0, 0);
-        if (n_it > 1) stage_dma(m0, n0, 1, 1);
+        stage_dma(m0, n0, 0);
+        if (n_it > 1) stage_dma(m0, n0, 1);
     }
     while (have) {
         f32x4 acc[TM][TN];
@@ -393,49 +482,63 @@ __global__ void __launch_bounds__(512) k_gemm_persist(GemmArgs g) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto mma = [&](bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        };
         // stage 0 of this tile has landed (stores of the previous epilogue drain here too: vmcnt is in-order)
-        if (n_it > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
-        else          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (n_it > 1) __builtin_amdgcn_s_waitcnt((NLOADS & 15) | 0x70 | ((NLOADS >> 4) << 14));
+        else          __builtin_amdgcn_s_waitcnt(0x0070);
         __builtin_amdgcn_s_barrier();
-        for (int it = 0; it < n_it; ++it) {
+        bf16x8 a0[TM], b0[TN], a1[TM], fb1[TN];
+        read_frags(buf, 0, a0, b0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        // software-pipelined K loop, same schedule as k_gemm_bf16's 3-stage ring
+        for (int it = 0; it + 2 < n_it; ++it) {
             int nb = buf + 2; nb = nb >= 3 ? nb - 3 : nb;
-            if (it + 2 < n_it) stage_dma(m0, n0, it + 2, nb);
-            const uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 af[TM], bfr[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = wm * WTM + i * 16 + (lane & 15);
-                    const int ch = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
-                    af[i] = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + ch * 16);
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int row = wn * (BN / 2) + j * 16 + (lane & 15);
-                    const int ch = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
-                    bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + ch * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
-            if (it + 1 < n_it) {
-                if (it + 2 < n_it) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOADS) : "memory");
-                else               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                buf = buf + 1 >= 3 ? 0 : buf + 1;
-            }
+            const int nx = buf == 2 ? 0 : buf + 1;
+            stage_dma(m0, n0, nb);
+            read_frags(buf, 1, a1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt((NLOADS & 15) | 0x70 | ((NLOADS >> 4) << 14));
+            __builtin_amdgcn_s_barrier();
+            read_frags(nx, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            buf = nx;
         }
+        if (n_it > 1) {
+            const int nx = buf == 2 ? 0 : buf + 1;
+            read_frags(buf, 1, a1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0070);
+            __builtin_amdgcn_s_barrier();
+            read_frags(nx, 0, a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            buf = nx;
+        }
+        read_frags(buf, 1, a1, fb1);
+        mma(a0, b0);
+        mma(a1, fb1);
         __builtin_amdgcn_s_barrier();            // every wave is done reading the ring: all three slots are free
         // prefetch the next tile's first two stages into the two slots after `buf`; the epilogue slab uses `buf`
         const bool nhave = tile_of(round + 1, nm0, nn0);
         int b1 = buf + 1 >= 3 ? 0 : buf + 1, b2 = b1 + 1 >= 3 ? 0 : b1 + 1;
         if (nhave) {
-            stage_dma(nm0, nn0, 0, b1);
-            if (n_it > 1) stage_dma(nm0, nn0, 1, b2);
+            d_seg = 0; d_k0 = 0;
+            stage_dma(nm0, nn0, b1);
+            if (n_it > 1) stage_dma(nm0, nn0, b2);
         }
         // ---- epilogue (LDS-transposed, 16 rows x 64 columns per wave per pass) ----
         {
