@@ -115,14 +115,14 @@ def main():
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             for k, v in json.load(f).items():
-                if k.startswith("k_gemm_bf16<256,128>") and S == 4 and (h, w, d) == (512, 512, 768):
+                if k.startswith("k_gemm_256 ") and S == 4 and (h, w, d) == (512, 512, 768):
                     traffic = v["traffic_bytes_per_launch"]
     except Exception:
         traffic = None
     roofline = None
     if kv_ms:
         ach = kv_flops / (kv_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "k_gemm_bf16<256,128,LDS-DMA,3-stage> (VATLiDAR.ca K|V projection, M=S*HW, N=2d, K=d)",
+        roofline = {"bound": "mfma", "kernel": "k_gemm_256 (256x256 tile, LDS-DMA, A ring 3 / W ring 2; VATLiDAR.ca K|V projection, M=S*HW, N=2d, K=d)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "traffic": traffic, "avg_launch_ms": round(kv_ms, 4), "flops_per_launch": kv_flops}
 

@@ -392,6 +392,225 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_bf16(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// 256x256 tile, 8 waves (2 x 4, wave tile 128 x 64), A ring of 3 x 32 KiB + W ring of 2 x 32 KiB = all 160 KiB of LDS.
+// Why: with the 256x128 tile the projections are bound by the L2 -> LDS fill (ablation on M=1M, N=1536, K=768:
+// the DMA + barriers alone take 3.0 of 3.15 ms), and fill bytes per MAC go as 1/BM + 1/BN -- this tile moves
+// 2/3 of the bytes.  Requires M % 256 == 0, N % 256 == 0, K % 64 == 0 and the vector epilogue (no clamps, no
+// predicates); everything else takes k_gemm_bf16.
+// Every A byte is an HBM (or Infinity-Cache) miss while W stays in L2: aliasing all A rows onto one row took the same
+// launch from 2.55 to 1.94 ms.  So the A stream is staged TWO K tiles ahead (3 slots) and the W stream one (2 slots),
+// issued W-before-A so that the in-order vmcnt can wait for "tile it+1" while the newest A tile stays in flight.
+// Schedule per K tile `it`, all waits after an MFMA cluster:
+//   read frags(tile it, k-half 1) | 32 MFMA (k-half 0) | vmcnt(4) lgkmcnt(0), barrier -> the slots of tile it are
+//   free and tile it+1 has landed | DMA W(it+2), A(it+3) | read frags(tile it+1, k-half 0) | 32 MFMA (k-half 1)
+// ---------------------------------------------------------------------------------------------------------
+template <int GELU>
+__device__ __forceinline__ void store_chunk8(const GemmArgs &g, int64_t z, int64_t row, int col, float (&v)[8]) {
+    if (g.bias) {
+        const float4 b0 = *reinterpret_cast<const float4 *>(g.bias + col), b1 = *reinterpret_cast<const float4 *>(g.bias + col + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    }
+    if (GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
+    const int64_t o = z * g.c_bs + row * g.ldc + col;
+    if (g.residual) {
+        const float4 r0 = *reinterpret_cast<const float4 *>(g.residual + o), r1 = *reinterpret_cast<const float4 *>(g.residual + o + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    if (g.rowtab) {
+        const float *t = g.rowtab + (row % g.rowtab_rows) * g.N + col;
+        const float4 t0 = *reinterpret_cast<const float4 *>(t), t1 = *reinterpret_cast<const float4 *>(t + 4);
+        v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+    }
+    if (g.c32) {
+        *reinterpret_cast<float4 *>(g.c32 + o) = *reinterpret_cast<float4 *>(v);
+        *reinterpret_cast<float4 *>(g.c32 + o + 4) = *reinterpret_cast<float4 *>(v + 4);
+    }
+    if (g.c16) {
+        const uint4 hb = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+        *reinterpret_cast<uint4 *>(g.c16 + o) = hb;
+        if (g.c16lo) {
+            const uint4 lb = make_uint4(pack_bf16(v[0] - __uint_as_float(hb.x << 16), v[1] - __uint_as_float(hb.x & 0xffff0000u)),
+                                        pack_bf16(v[2] - __uint_as_float(hb.y << 16), v[3] - __uint_as_float(hb.y & 0xffff0000u)),
+                                        pack_bf16(v[4] - __uint_as_float(hb.z << 16), v[5] - __uint_as_float(hb.z & 0xffff0000u)),
+                                        pack_bf16(v[6] - __uint_as_float(hb.w << 16), v[7] - __uint_as_float(hb.w & 0xffff0000u)));
+            *reinterpret_cast<uint4 *>(g.c16lo + o) = lb;
+        }
+    }
+}
+
+template <int GELU>
+__global__ void __launch_bounds__(512) k_gemm_256(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 64, NW = 8;
+    constexpr int TM = 8, TN = 4;                   // 16x16 MFMA tiles per wave: 128 rows x 64 columns
+    constexpr int ASLOT = BM * 128, WSLOT = BN * 128;          // 32 KiB each
+    constexpr int WBASE = 3 * ASLOT;                // A ring: 3 slots at 0; W ring: 2 slots behind it (160 KiB in all)
+    constexpr int NA = BM / (8 * NW), NWL = BN / (8 * NW);     // global_load_lds per wave per A / W tile (4, 4)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(tile / g.ntx) * BM;
+    const int n0 = (tile % g.ntx) * BN;
+    const int64_t z = blockIdx.z;
+    const int nk = g.K / BK;
+    const int n_it = nk * g.nseg;
+
+    // DMA source: lane (r8, pch) of wave `wid` fetches the 16-byte chunk pch ^ swz(row) of row piece*8 + r8, piece = i*8 + wid;
+    // (row >> 1) & 7 depends on (wid & 1, r8) only, so the swizzled per-lane base pointer is fixed and pieces / K tiles /
+    // split segments are uniform offsets on top of it
+    const int r8 = lane >> 3, pch = lane & 7;
+    const int sw = (pch ^ ((((wid & 1) << 2) + (r8 >> 1)) & 7)) << 3;
+    const uint16_t *pa = g.a[0] + z * g.a_bs + (m0 + wid * 8 + r8) * g.lda + sw;
+    const uint16_t *pw = g.w[0] + z * g.w_bs + (int64_t)(n0 + wid * 8 + r8) * g.ldw + sw;
+    const int64_t dA1 = g.a[1] - g.a[0], dA2 = g.a[2] - g.a[0], dW1 = g.w[1] - g.w[0], dW2 = g.w[2] - g.w[0];
+    const int64_t a_step = 64 * g.lda, w_step = 64 * g.ldw;
+    // the A stream (HBM misses: every A byte is new) runs TWO tiles ahead, the W stream (L2 hits) one; each keeps its own
+    // in-order (segment, k0) cursor
+    int a_seg = 0, a_k0 = 0, w_seg = 0, w_k0 = 0;
+    // tile cursors: *_next() returns the source of the next tile of the stream and advances; *_piece() issues one 1-KiB
+    // global_load_lds of it (pieces are issued one per MFMA row inside the K loop, never as a burst: a burst of 8 per wave x 8
+    // waves back-pressures the VMEM issue port and holds up the LDS reads + MFMAs queued behind it)
+    auto a_next = [&]() __attribute__((always_inline)) -> const uint16_t * {
+        const uint16_t *A = pa + (a_seg == 0 ? (int64_t)0 : a_seg == 1 ? dA1 : dA2) + a_k0;
+        a_k0 += BK;
+        if (a_k0 >= nk * BK) { a_k0 = 0; ++a_seg; }
+        return A;
+    };
+    auto w_next = [&]() __attribute__((always_inline)) -> const uint16_t * {
+        const uint16_t *W = pw + (w_seg == 0 ? (int64_t)0 : w_seg == 1 ? dW1 : dW2) + w_k0;
+        w_k0 += BK;
+        if (w_k0 >= nk * BK) { w_k0 = 0; ++w_seg; }
+        return W;
+    };
+    auto a_piece = [&](const uint16_t *A, int slot, int i) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A + i * a_step),
+                                         (__attribute__((address_space(3))) void *)(smem + slot * ASLOT + wid * 1024 + i * (NW * 1024)), 16, 0, 0);
+    };
+    auto w_piece = [&](const uint16_t *W, int slot, int i) __attribute__((always_inline)) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(W + i * w_step),
+                                         (__attribute__((address_space(3))) void *)(smem + WBASE + slot * WSLOT + wid * 1024 + i * (NW * 1024)), 16, 0, 0);
+    };
+    auto dma_a = [&](int slot) __attribute__((always_inline)) {
+        const uint16_t *A = a_next();
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a_piece(A, slot, i);
+    };
+    auto dma_w = [&](int slot) __attribute__((always_inline)) {
+        const uint16_t *W = w_next();
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) w_piece(W, slot, i);
+    };
+    // fragment addresses: row*128 + ((ks*4 + (lane>>4)) ^ ((row>>1)&7))*16; row = base16 + (lane&15) with base16 % 16 == 0, so the
+    // XOR term depends on the lane only and k-half 1 is the same address with bit 6 flipped
+    const int frow = lane & 15;
+    const int fx = (((lane >> 4) ^ ((frow >> 1) & 7)) << 4);
+    const int fa = (wm * 128 + frow) * 128 + fx;                 // + i*2048
+    const int fb = WBASE + (wn * 64 + frow) * 128 + fx;          // + j*2048
+    auto read_frags = [&](int as, int ws, int ks, bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) __attribute__((always_inline)) {
+        const uint8_t *sa = smem + as * ASLOT, *sb = smem + ws * WSLOT;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(sa + ((fa + i * 2048) ^ (ks << 6)));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + ((fb + j * 2048) ^ (ks << 6)));
+    };
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mma = [&](bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    };
+    constexpr int WAIT_A = (NA & 15) | 0x70 | ((NA >> 4) << 14);           // vmcnt(NA) lgkmcnt(0): one A tile stays in flight
+    constexpr int WAIT_0 = 0x0070;                                         // vmcnt(0) lgkmcnt(0)
+
+    // queue order A0 W0 A1 W1 A2: vmcnt is in-order, so "tile t landed" = everything but the newer A tile(s) has returned
+    dma_a(0); dma_w(0);
+    if (n_it > 2) {
+        dma_a(1); dma_w(1); dma_a(2);
+        __builtin_amdgcn_s_waitcnt(((2 * NA + NWL) & 15) | 0x70 | (((2 * NA + NWL) >> 4) << 14));
+    } else if (n_it > 1) {
+        dma_a(1); dma_w(1);
+        __builtin_amdgcn_s_waitcnt(((NA + NWL) & 15) | 0x70 | (((NA + NWL) >> 4) << 14));
+    } else {
+        __builtin_amdgcn_s_waitcnt(WAIT_0);
+    }
+    __builtin_amdgcn_s_barrier();
+    bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+    read_frags(0, 0, 0, a0, b0);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    int as = 0, ws = 0;
+    // one K tile: k-half 1 fragments | 32 MFMA | wait + barrier (tile it+1 landed, tile it fully read) | refill the two slots
+    // just drained | k-half 0 fragments of tile it+1 | 32 MFMA.  Flags are literal at every call site (branch-free bodies).
+    auto k_tile = [&](bool issue_w, bool issue_a, bool a_in_flight) __attribute__((always_inline)) {
+        const int an = as == 2 ? 0 : as + 1;
+        read_frags(as, ws, 1, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (a_in_flight) __builtin_amdgcn_s_waitcnt(WAIT_A); else __builtin_amdgcn_s_waitcnt(WAIT_0);
+        __builtin_amdgcn_s_barrier();
+        const uint16_t *Wn = issue_w ? w_next() : nullptr;     // W tile it+2 (older in the queue than ...)
+        const uint16_t *An = issue_a ? a_next() : nullptr;     // ... A tile it+3
+        read_frags(an, ws ^ 1, 0, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        static_assert(NWL + NA == TM, "one DMA piece per MFMA row");
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            if (i < NWL) { if (issue_w) w_piece(Wn, ws, i); }
+            else         { if (issue_a) a_piece(An, as, i - NWL); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // a0/b0 landed under the MFMAs (the DMAs stay in flight)
+        as = an; ws ^= 1;
+    };
+    for (int it = 0; it + 3 < n_it; ++it) k_tile(true, true, true);
+    if (n_it >= 3) k_tile(true, false, true);
+    if (n_it >= 2) k_tile(false, false, false);
+    read_frags(as, ws, 1, a1, b1);
+    mma(a0, b0);
+    mma(a1, b1);
+    __builtin_amdgcn_s_barrier();                              // the epilogue reuses the A ring as its transpose slab
+
+    // ---- epilogue: 16 rows x 64 columns per wave per pass through a wave-private LDS slab, 16/32-byte stores ----
+    constexpr int HR = 16, WC = 64, LDE = WC + 4, CPR = WC / 8;
+    static_assert(NW * HR * LDE * 4 <= 3 * ASLOT, "epilogue slab must fit in the A ring");
+    float *ep = reinterpret_cast<float *>(smem) + wid * (HR * LDE);
+#pragma unroll
+    for (int ii = 0; ii < TM; ++ii) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                ep[((lane >> 4) * 4 + r) * LDE + j * 16 + (lane & 15)] = acc[ii][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int p = 0; p < (HR * CPR) / 64; ++p) {
+            const int q = p * 64 + lane, rr = q / CPR, c8 = q % CPR;
+            float v[8];
+            *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8);
+            *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8 + 4);
+            store_chunk8<GELU>(g, z, m0 + wm * 128 + ii * 16 + rr, n0 + wn * WC + c8 * 8, v);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Persistent 256x128 GEMM (8 waves, 3-stage LDS ring, counted vmcnt) for the big projections.
 // One workgroup per CU walks a strided sequence of tiles.  The ring keeps running across tile boundaries: the
 // first two K-stages of the NEXT tile are issued BEFORE the current tile's epilogue, so the epilogue's LDS
@@ -833,6 +1052,25 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
     // 256x128 / 8 waves / 3 stages when there is enough work to fill the chip with the bigger tile
     const bool huge = dma && lvq_cdiv(m, 256) * lvq_cdiv(n, 128) * batch >= 512 && getenv("LVQ_GEMM_NO256") == nullptr;
     if (batch > 65535) return LVQ_EUNSUPPORTED;
+    // 256x256 / two 64-KiB slots: 2/3 of the L2->LDS fill bytes of the 256x128 tile (the bound on these projections);
+    // whole tiles only, and enough of them that the coarser grid still fills the 256 CUs several times over
+    static int ok256 = -1;          // -1 unknown, 0 the runtime refused 160 KiB of dynamic LDS, 1 usable
+    if (dma && g.vec_epilogue && m % 256 == 0 && n % 256 == 0 && (m / 256) * (n / 256) * batch >= 1024 &&
+        (m / 256) * (n / 256) <= 0x7fffffff && ok256 != 0 && getenv("LVQ_GEMM_NO256X256") == nullptr && getenv("LVQ_GEMM_NO256") == nullptr) {
+        const size_t lds = (size_t)5 * 256 * 128;              // A ring 3 x 32 KiB + W ring 2 x 32 KiB
+        if (ok256 < 0)
+            ok256 = hipFuncSetAttribute((const void *)k_gemm_256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                    hipFuncSetAttribute((const void *)k_gemm_256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+        if (ok256) {
+            g.ntx = (int)(n / 256);
+            g.ntiles = (m / 256) * (n / 256);
+            dim3 grid((unsigned)g.ntiles, 1, (unsigned)batch);
+            if (ge) hipLaunchKernelGGL(k_gemm_256<1>, grid, dim3(512), lds, st, g);
+            else    hipLaunchKernelGGL(k_gemm_256<0>, grid, dim3(512), lds, st, g);
+            return lvq_launch_status();
+        }
+        (void)hipGetLastError();
+    }
     if (huge) {
         const int64_t tiles = lvq_cdiv(n, 128) * lvq_cdiv(m, 256);
         if (tiles > 0x7fffffff) return LVQ_EUNSUPPORTED;

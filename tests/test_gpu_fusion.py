@@ -46,7 +46,9 @@ def dev(a):
 # unit kernels
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m,n,k", [(64, 64, 64), (128, 128, 128), (200, 136, 72), (1, 8, 8), (333, 768, 768),
-                                   (4096, 1536, 768), (130, 3072, 768), (196, 64, 2048), (1000, 776, 8)])
+                                   (4096, 1536, 768), (130, 3072, 768), (196, 64, 2048), (1000, 776, 8),
+                                   # >= 1024 whole 256x256 tiles: the two-slot k_gemm_256 path (1, 2, 3, 6, 9 K tiles)
+                                   (8192, 8192, 64), (65536, 1024, 128), (16384, 4096, 192)])
 @pytest.mark.parametrize("split", [False, True])
 def test_gemm_exact(m, n, k, split):
     o = ops()
@@ -76,6 +78,21 @@ def test_gemm_epilogues_and_slices():
     z = a.double().cpu() @ w.double().cpu()[n:2 * n].t() + bias.double().cpu()[n:2 * n]
     ref = 0.5 * (0.5 * z * (1 + torch.erf(z / math.sqrt(2)))) + tab.double().cpu()[torch.arange(m) % 50]
     assert (y.double().cpu() - ref).abs().max().item() < 1e-5
+
+
+def test_gemm_256_tile_epilogue():
+    """GELU + alpha + row table + batch slices on the 256x256-tile kernel (M, N multiples of 256, >= 1024 tiles)."""
+    o = ops()
+    m, n, k = 32768, 2048, 128
+    a = bf_round(torch.from_numpy(synth.randn((m, k), 15))).to(DEV)
+    w = bf_round(torch.from_numpy(synth.randn((n, k), 16, 0.2))).to(DEV)
+    bias = torch.from_numpy(synth.randn((n,), 17)).to(DEV)
+    tab = torch.from_numpy(synth.randn((512, n), 18)).to(DEV)
+    y, yb = o.linear(o.cast(a, False), o.cast(w, False), bias, gelu=True, alpha=0.5, rowtab=tab, out_f32=True, out_bf=True)
+    z = a.double().cpu() @ w.double().cpu().t() + bias.double().cpu()
+    ref = 0.5 * (0.5 * z * (1 + torch.erf(z / math.sqrt(2)))) + tab.double().cpu()[torch.arange(m) % 512]
+    assert (y.double().cpu() - ref).abs().max().item() < 2e-5
+    assert (o.to_f32(yb).double().cpu() - ref).abs().max().item() < 1e-2 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("rows,d", [(1, 8), (7, 96), (1000, 768), (130, 2048), (5, 896)])
