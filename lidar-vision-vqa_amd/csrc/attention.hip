@@ -74,7 +74,11 @@ __device__ __forceinline__ float max_over_groups(float x) {
 template <int DHP, int NSPLIT, int QT, int NW>
 __global__ void __launch_bounds__(NW * 64) k_attn(AttnArgs a) {
     constexpr int NS = (NSPLIT == 3) ? 2 : 1;
-    constexpr int KROW = DHP + 8;       // bf16 elements per K / V row (+16 B pad: odd multiple of 16 B)
+    // K / V rows in LDS.  DHP == 64: unpadded 128-byte rows with the 16-byte chunk index XORed by (row & 6) -- conflict-free
+    // for BOTH the ds_read_b128 K reads (16-lane groups {0-3,12-15,20-27}, ...) and the ds_read_b64_tr_b16 V reads (the +16 B
+    // pad left both 2-way: SQ_LDS_BANK_CONFLICT was 40 % of the LDS cycles).  Other head dims keep the padded rows.
+    constexpr bool SWZ = DHP == 64 && NW >= 8;
+    constexpr int KROW = SWZ ? DHP : DHP + 8;       // bf16 elements per K / V row
     constexpr int NC = DHP / 32;        // 32-wide k chunks of the head dim
     constexpr int ND = DHP / 16;        // 16-wide output tiles of the head dim
     constexpr int QW = 16 * QT;         // queries per wave
@@ -92,7 +96,13 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnArgs a) {
     const int sp = grp % a.nsplit, h = (grp / a.nsplit) % a.H, b = grp / (a.nsplit * a.H);
     const int hk = h / (a.H / a.Hkv);
     const int q0 = qtile * (NW * QW) + wid * QW;
-    const float cexp = a.scale * 1.4426950408889634f;   // scores are exponentiated in the log2 domain
+    // plain-bf16 mode: Q is pre-multiplied by scale*log2(e) once (re-rounded to bf16), so the MFMA output is already the
+    // exponent argument and the per-score v_fma disappears from the softmax (the loop is VALU-issue-bound: ~17 exp + ~75
+    // other vector issues against 18 MFMAs per 64-key tile).  bf16x3 keeps exact operands and scales in fp32.
+    constexpr bool FAST = NSPLIT == 1;
+    const float cexp0 = a.scale * 1.4426950408889634f;  // scores are exponentiated in the log2 domain
+    const float cexp = FAST ? 1.0f : cexp0;
+    const float bias_mul = FAST ? 1.4426950408889634f : 1.0f / a.scale;   // bias enters before the cexp multiply
 
     // Q fragments (B operand of S^T = K Q^T): lane supplies Q[q0 + qt*16 + l15][c*32 + 8g .. +7]
     bf16x8 qf[NS][QT][NC];
@@ -108,6 +118,12 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnArgs a) {
                     uint4 v = make_uint4(0, 0, 0, 0);
                     if (qi < a.Nq && kk < a.dh)
                         v = *reinterpret_cast<const uint4 *>(src[s] + (int64_t)b * a.q_bs + (int64_t)qi * a.ldq + (int64_t)h * a.q_hs + kk);
+                    if (FAST) {
+                        uint32_t *w = reinterpret_cast<uint32_t *>(&v);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            w[e] = pack_bf16(__uint_as_float(w[e] << 16) * cexp0, __uint_as_float(w[e] & 0xffff0000u) * cexp0);
+                    }
                     qf[s][qt][c] = *reinterpret_cast<bf16x8 *>(&v);
                 }
     }
@@ -158,11 +174,13 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnArgs a) {
         live[i] = (e < KVB * CH) && (kk < a.dh);        // head-dim padding chunks stay zero
         koff[i] = (uint32_t)((r * a.ldk + kk) * 2);
         voff[i] = (uint32_t)((r * a.ldv + kk) * 2);
-        lso[i] = (uint32_t)(r * KROW + kk);
+        lso[i] = (uint32_t)(r * KROW + (SWZ ? ((kk >> 3) ^ (r & 6)) << 3 : kk));
     }
     const uint32_t ktile = (uint32_t)(KVB * a.ldk * 2), vtile = (uint32_t)(KVB * a.ldv * 2);
-    i32x4 sk[NS][NLD], sv[NS][NLD];
-    auto gload = [&](int t) {
+    // two register sets: the loads of tile t+2 are in flight while tile t is computed and tile t+1 (the other set) is written to
+    // LDS -- with one set the loop ran at one HBM/Infinity-Cache round trip per 64-key tile (~1.3 us)
+    i32x4 skA[NS][NLD], svA[NS][NLD], skB[NS][NLD], svB[NS][NLD];
+    auto gload = [&](int t, i32x4 (&sk)[NS][NLD], i32x4 (&sv)[NS][NLD]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
 #pragma unroll
@@ -175,7 +193,7 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnArgs a) {
                 }
             }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, i32x4 (&sk)[NS][NLD], i32x4 (&sv)[NS][NLD]) __attribute__((always_inline)) {
         uint16_t *kd = smem + buf * TILE_E, *vd = kd + NS * KVB * KROW;
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
@@ -191,19 +209,31 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnArgs a) {
     // ---- one 64-key tile.  MASKED = false: every key is valid and visible, no bias (the common case) ----
     auto tile = [&](const uint16_t *Ks, const uint16_t *Vs, int t, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
+        // element offset inside a V row of the 4 columns that lane 4q+p (q = l15>>2, p = l15&3) addresses for d-block n; the
+        // row is (multiple of 16) + 4g + q, so its swizzle key (row & 6) is (4g + q) & 6 for every sub-tile
+        auto vcol = [&](int n) { return SWZ ? ((((2 * n + ((l15 & 3) >> 1)) ^ ((4 * g + (l15 >> 2)) & 6)) << 3) + 4 * (l15 & 1)) : n * 16 + 4 * (l15 & 3); };
         const int kleft = a.Nkv - t * KVB;
         const int nkt = (!MASKED || kleft >= KVB) ? 4 : (kleft + 15) >> 4;   // 16-key sub-tiles holding a valid key
+        // DEFER (unmasked plain-bf16 tiles): the score accumulators start at -m_run, so the MFMA result is s - m_run and goes
+        // straight into v_exp_f32; the running max only moves (and O / l are only rescaled) when a tile exceeds it by more than
+        // DEFER_THR in the log2 domain, i.e. P <= 2^DEFER_THR -- fp32 accumulation and bf16's 8-bit exponent have the headroom.
+        // The rare rescale tile runs its own copy of the P V product, so the common path accumulates O in place.
+        constexpr bool DEFER = FAST && !MASKED && QT == 1 && NW >= 8;   // (4-wave kernels: short K/V, registers go to occupancy)
+        constexpr float DEFER_THR = 6.0f;
+        const bool fresh = DEFER && m_run[0] == -INFINITY;        // first tile of this split: no reference yet
+        const float sinit = (DEFER && !fresh) ? -m_run[0] : 0.f;
         f32x4 sc[4][QT];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) sc[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int qt = 0; qt < QT; ++qt) sc[kt][qt] = f32x4{sinit, sinit, sinit, sinit};
             if (!MASKED || kt < nkt) {
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const bf16x8 kh = *reinterpret_cast<const bf16x8 *>(Ks + (kt * 16 + l15) * KROW + c * 32 + g * 8);
+                    const int kcol = SWZ ? (((c * 4 + g) ^ (l15 & 6)) << 3) : c * 32 + g * 8;
+                    const bf16x8 kh = *reinterpret_cast<const bf16x8 *>(Ks + (kt * 16 + l15) * KROW + kcol);
                     bf16x8 kl;
-                    if (NSPLIT == 3) kl = *reinterpret_cast<const bf16x8 *>(Ks + (KVB + kt * 16 + l15) * KROW + c * 32 + g * 8);
+                    if (NSPLIT == 3) kl = *reinterpret_cast<const bf16x8 *>(Ks + (KVB + kt * 16 + l15) * KROW + kcol);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
                         sc[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh, qf[0][qt][c], sc[kt][qt], 0, 0, 0);
@@ -215,7 +245,114 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnArgs a) {
                 }
             }
         }
+        // V^T fragments of the whole tile are fetched BEFORE the softmax VALU section (32 VGPRs at dh = 64): issued after
+        // it, every PV MFMA sat behind its own ds_read + lgkmcnt(0)
+        constexpr bool PRE = !MASKED && NSPLIT == 1 && QT == 1 && ND <= 4 && NW >= 8;
+        bf16x8 vpre[PRE ? 2 : 1][PRE ? ND : 1];
+        if (PRE) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint16_t *vbase = Vs + ((2 * s2) * 16 + 4 * g + (l15 >> 2)) * KROW;
+#pragma unroll
+                for (int n = 0; n < ND; ++n) {
+                    const uint16_t *va = vbase + vcol(n);
+                    bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)va);
+                    bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)(va + 16 * KROW));
+                    vpre[s2][n] = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         uint32_t pk[QT][4][2], pkl[QT][4][2];   // packed bf16 P^T [qt][kt][pair], hi and (bf16x3) lo parts
+
+        // O^T += V^T P^T : A = V^T[d][keys] via the transposing LDS read, B = P^T straight from the registers.
+        // k index of step s2, element j of lane group g  <->  key (2*s2 + (j>>2))*16 + 4g + (j&3)   (both operands)
+        auto pv = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (!MASKED || 2 * s2 < nkt) {
+                    bf16x8 pf[QT], pfl[QT];
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        uint4 u = make_uint4(pk[qt][2 * s2][0], pk[qt][2 * s2][1], pk[qt][2 * s2 + 1][0], pk[qt][2 * s2 + 1][1]);
+                        pf[qt] = *reinterpret_cast<bf16x8 *>(&u);
+                        if (NSPLIT == 3) {
+                            uint4 ul = make_uint4(pkl[qt][2 * s2][0], pkl[qt][2 * s2][1], pkl[qt][2 * s2 + 1][0], pkl[qt][2 * s2 + 1][1]);
+                            pfl[qt] = *reinterpret_cast<bf16x8 *>(&ul);
+                        }
+                    }
+                    // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of its group's 4-key x 16-d block
+                    const uint16_t *vbase = Vs + ((2 * s2) * 16 + 4 * g + (l15 >> 2)) * KROW;
+#pragma unroll
+                    for (int n = 0; n < ND; ++n) {
+                        const uint16_t *va = vbase + vcol(n);
+                        bf16x8 vh;
+                        if (PRE) {
+                            vh = vpre[PRE ? s2 : 0][PRE ? n : 0];
+                        } else {
+                            bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)va);
+                            bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)(va + 16 * KROW));
+                            vh = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+                        bf16x8 vlo;
+                        if (NSPLIT == 3) {
+                            bf16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)(va + KVB * KROW));
+                            bf16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)(va + (KVB + 16) * KROW));
+                            vlo = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
+                        }
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) {
+                            o[n][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pf[qt], o[n][qt], 0, 0, 0);
+                            if (NSPLIT == 3) {
+                                o[n][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pfl[qt], o[n][qt], 0, 0, 0);
+                                o[n][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vlo, pf[qt], o[n][qt], 0, 0, 0);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {     // row sums: the ones-row of V^T
+                        o[ND][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qt], o[ND][qt], 0, 0, 0);
+                        if (NSPLIT == 3) o[ND][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pfl[qt], o[ND][qt], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        auto row_max = [&](int qt) __attribute__((always_inline)) {
+            float tmax = fmaxf(fmaxf(sc[0][qt][0], sc[0][qt][1]), fmaxf(sc[0][qt][2], sc[0][qt][3]));
+#pragma unroll
+            for (int kt = 1; kt < 4; ++kt)
+                tmax = fmaxf(fmaxf(fmaxf(tmax, sc[kt][qt][0]), fmaxf(sc[kt][qt][1], sc[kt][qt][2])), sc[kt][qt][3]);
+            return max_over_groups(tmax);
+        };
+        auto exp_pack = [&](int qt) __attribute__((always_inline)) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                pk[qt][kt][0] = pack_bf16(fast_exp2(sc[kt][qt][0]), fast_exp2(sc[kt][qt][1]));
+                pk[qt][kt][1] = pack_bf16(fast_exp2(sc[kt][qt][2]), fast_exp2(sc[kt][qt][3]));
+            }
+        };
+
+        if (DEFER) {
+            const float tmax = row_max(0);                        // relative to m_run (absolute on the first tile)
+            if (__any(fresh || tmax > DEFER_THR)) {               // rare: move the reference of the rows that need it
+                const float delta = fresh ? tmax : fmaxf(tmax, 0.f);
+                const float al = fresh ? 1.0f : fast_exp2(-delta);
+                m_run[0] = (fresh ? 0.f : m_run[0]) + delta;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sc[kt][0][r] -= delta;
+#pragma unroll
+                for (int n = 0; n <= ND; ++n) o[n][0] *= al;
+                exp_pack(0);
+                pv();
+            } else {
+                exp_pack(0);
+                pv();
+            }
+            return;
+        }
+
         bool any_grow = false;
         float alpha[QT];
 #pragma unroll
@@ -228,15 +365,11 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnArgs a) {
                     for (int r = 0; r < 4; ++r) {
                         const int key = t * KVB + kt * 16 + g * 4 + r;
                         if (a.bias && key < a.Nkv && qi < a.Nq)   // folded so that one fma(x, cexp, -m) serves both terms
-                            sc[kt][qt][r] += a.bias[(((int64_t)b * a.H + h) * a.Nq + qi) * a.Nkv + key] / a.scale;
+                            sc[kt][qt][r] += a.bias[(((int64_t)b * a.H + h) * a.Nq + qi) * a.Nkv + key] * bias_mul;
                         if (key >= a.Nkv || (a.causal && key > qi + a.Nkv - a.Nq)) sc[kt][qt][r] = -INFINITY;
                     }
             }
-            float tmax = fmaxf(fmaxf(sc[0][qt][0], sc[0][qt][1]), fmaxf(sc[0][qt][2], sc[0][qt][3]));
-#pragma unroll
-            for (int kt = 1; kt < 4; ++kt)
-                tmax = fmaxf(fmaxf(fmaxf(tmax, sc[kt][qt][0]), fmaxf(sc[kt][qt][1], sc[kt][qt][2])), sc[kt][qt][3]);
-            tmax = max_over_groups(tmax);
+            const float tmax = row_max(qt);
             const float m_new = fmaxf(m_run[qt], tmax * cexp);
             const float m_safe = (MASKED && m_new == -INFINITY) ? 0.f : m_new;
             alpha[qt] = fast_exp2(m_run[qt] - m_safe);
@@ -255,73 +388,50 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnArgs a) {
                 }
             }
         }
-        // rescale the accumulators only when some running max moved (exact: alpha == 1 otherwise)
-        if (__any(any_grow)) {
+        // rescale the accumulators (masked tiles: only when some running max moved -- alpha == 1 exactly otherwise; the
+        // unmasked form is unconditional: the branch made the compiler copy all of O around it every tile)
+        if (MASKED ? __any(any_grow) : true) {
 #pragma unroll
             for (int n = 0; n <= ND; ++n)
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) o[n][qt] *= alpha[qt];
         }
-        // O^T += V^T P^T : A = V^T[d][keys] via the transposing LDS read, B = P^T straight from the registers.
-        // k index of step s2, element j of lane group g  <->  key (2*s2 + (j>>2))*16 + 4g + (j&3)   (both operands)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            if (!MASKED || 2 * s2 < nkt) {
-                bf16x8 pf[QT], pfl[QT];
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    uint4 u = make_uint4(pk[qt][2 * s2][0], pk[qt][2 * s2][1], pk[qt][2 * s2 + 1][0], pk[qt][2 * s2 + 1][1]);
-                    pf[qt] = *reinterpret_cast<bf16x8 *>(&u);
-                    if (NSPLIT == 3) {
-                        uint4 ul = make_uint4(pkl[qt][2 * s2][0], pkl[qt][2 * s2][1], pkl[qt][2 * s2 + 1][0], pkl[qt][2 * s2 + 1][1]);
-                        pfl[qt] = *reinterpret_cast<bf16x8 *>(&ul);
-                    }
-                }
-                // lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of its group's 4-key x 16-d block
-                const uint16_t *vbase = Vs + ((2 * s2) * 16 + 4 * g + (l15 >> 2)) * KROW + 4 * (l15 & 3);
-#pragma unroll
-                for (int n = 0; n < ND; ++n) {
-                    const uint16_t *va = vbase + n * 16;
-                    bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)va);
-                    bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)(va + 16 * KROW));
-                    const bf16x8 vh = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    bf16x8 vlo;
-                    if (NSPLIT == 3) {
-                        bf16x4 w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)(va + KVB * KROW));
-                        bf16x4 w1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4 *)(va + (KVB + 16) * KROW));
-                        vlo = __builtin_shufflevector(w0, w1, 0, 1, 2, 3, 4, 5, 6, 7);
-                    }
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) {
-                        o[n][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pf[qt], o[n][qt], 0, 0, 0);
-                        if (NSPLIT == 3) {
-                            o[n][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh, pfl[qt], o[n][qt], 0, 0, 0);
-                            o[n][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vlo, pf[qt], o[n][qt], 0, 0, 0);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {     // row sums: the ones-row of V^T
-                    o[ND][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[qt], o[ND][qt], 0, 0, 0);
-                    if (NSPLIT == 3) o[ND][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pfl[qt], o[ND][qt], 0, 0, 0);
-                }
-            }
-        }
+        pv();
     };
 
-    // K/V tiles are double-buffered in LDS: the loads of tile t+1 are issued before the MFMAs of tile t and written
-    // to the other buffer after them (issue-early / write-late), one barrier per tile.
-    if (t0 < t1) { gload(t0); lstore(0); }
-    __syncthreads();
+    // K/V tiles are double-buffered in LDS and double-buffered again in registers: tile t+2 is requested before the MFMAs of
+    // tile t, tile t+1 (requested one tile earlier) is written to the other LDS buffer after them; one barrier per tile.
     const bool special = a.bias != nullptr || a.causal;
-    for (int t = t0; t < t1; ++t) {
-        const int buf = (t - t0) & 1;
+    auto step = [&](int t, int buf) __attribute__((always_inline)) {
         const uint16_t *Ks = smem + buf * TILE_E, *Vs = Ks + NS * KVB * KROW;
-        if (t + 1 < t1) gload(t + 1);
         if (special || (t + 1) * KVB > a.Nkv) tile(Ks, Vs, t, std::true_type{});
         else tile(Ks, Vs, t, std::false_type{});
-        if (t + 1 < t1) lstore(buf ^ 1);
+    };
+    constexpr bool DEEP = NW >= 8;       // the many-wave forms serve the long K/V streams; short ones keep registers for occupancy
+    if (t0 < t1) { gload(t0, skA, svA); lstore(0, skA, svA); }
+    if (DEEP) {
+        if (t0 + 1 < t1) gload(t0 + 1, skB, svB);
         __syncthreads();
+        for (int t = t0; t < t1; t += 2) {
+            if (t + 2 < t1) gload(t + 2, skA, svA);
+            step(t, 0);
+            if (t + 1 < t1) lstore(1, skB, svB);
+            __syncthreads();
+            if (t + 1 >= t1) break;
+            if (t + 3 < t1) gload(t + 3, skB, svB);
+            step(t + 1, 1);
+            if (t + 2 < t1) lstore(0, skA, svA);
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        for (int t = t0; t < t1; ++t) {
+            const int buf = (t - t0) & 1;
+            if (t + 1 < t1) gload(t + 1, skA, svA);
+            step(t, buf);
+            if (t + 1 < t1) lstore(buf ^ 1, skA, svA);
+            __syncthreads();
+        }
     }
 
     // ---- write back: lane holds O[q0 + qt*16 + l15][n*16 + g*4 + r]; o[ND][qt][*] = l ----
@@ -425,6 +535,11 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split) 
         const int f = atoi(ev);
         if ((f == 4 || f == 8 || f == 12) && p.qt == 1 && dhp <= 64) p.nw = f;
     }
+    if (const char *ev = getenv("LVQ_ATTN_WIDE")) {    // experiment: 12 waves x (2|3) query tiles per wave
+        const int f = atoi(ev);
+        if (f == 2 && dhp == 64 && !split) { p.qt = 2; p.nw = 12; }
+        if (f == 9 && dhp == 64 && !split) { p.qt = 2; p.nw = 9; }
+    }
     p.nqt = (nq + 16 * p.nw * p.qt - 1) / (16 * p.nw * p.qt);
     const int64_t base = (int64_t)p.nqt * n_heads * batch;
     const int n_tiles = (nkv + KVB - 1) / KVB;
@@ -440,7 +555,7 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split) 
 
 template <int DHP, int NSPLIT, int QT, int NW> int launch_attn_qt(AttnArgs &a, hipStream_t st) {
     constexpr int NS = (NSPLIT == 3) ? 2 : 1;
-    const size_t lds = (size_t)(2 * 2 * NS * KVB * (DHP + 8)) * sizeof(uint16_t);   // two K+V stages
+    const size_t lds = (size_t)(2 * 2 * NS * KVB * ((DHP == 64 && NW >= 8) ? DHP : DHP + 8)) * sizeof(uint16_t);   // two K+V stages
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void *)k_attn<DHP, NSPLIT, QT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int64_t nwg = (int64_t)a.B * a.H * a.nsplit * a.nqt;
@@ -459,6 +574,8 @@ template <int DHP, int NSPLIT> int launch_attn(AttnArgs &a, const AttnPlan &pl, 
         if (pl.nw == 12) return launch_attn_qt<DHP, NSPLIT, 1, (DHP <= 64) ? 12 : 4>(a, st);
         if (pl.nw == 8) return launch_attn_qt<DHP, NSPLIT, 1, (DHP <= 64) ? 8 : 4>(a, st);
     }
+    if (DHP == 64 && NSPLIT == 1 && pl.nw == 9 && pl.qt == 2) return launch_attn_qt<DHP, NSPLIT, (DHP == 64 && NSPLIT == 1) ? 2 : 1, (DHP == 64 && NSPLIT == 1) ? 9 : 4>(a, st);
+    if (DHP == 64 && NSPLIT == 1 && pl.nw == 12 && pl.qt == 2) return launch_attn_qt<DHP, NSPLIT, (DHP == 64 && NSPLIT == 1) ? 2 : 1, (DHP == 64 && NSPLIT == 1) ? 12 : 4>(a, st);
     if (!(DHP > 64 && NSPLIT == 3) && pl.qt >= 2) return launch_attn_qt<DHP, NSPLIT, (DHP > 64 && NSPLIT == 3) ? 1 : 2, 4>(a, st);
     return launch_attn_qt<DHP, NSPLIT, 1, 4>(a, st);
 }
