@@ -20,6 +20,7 @@ oracle/ timed on the host cores on a bounded sample) and the headline cross-atte
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -83,6 +84,11 @@ def main():
         step()
     torch.cuda.synchronize()
     ops.EVENTS = {}
+    # a full CPython cycle collection (~30 ms with torch's module graph alive) otherwise lands inside the timed steps every
+    # dozen iterations and stalls the launch stream: collect now, keep the survivors out of later scans
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -97,6 +103,7 @@ def main():
     value = world * tokens_per_step * args.steps / dt
 
     if rank != 0:
+        gc.enable()
         D.finalize()
         return
 
@@ -192,6 +199,7 @@ def main():
         err = (out["fused"][0].cpu() - ref["fused"][0]).abs().max().item()
         result["parity_vs_cpu"] = {"dtype": args.precision, "fused_max_abs_err": round(err, 6),
                                    "fused_ref_absmax": round(ref["fused"].abs().max().item(), 4)}
+    gc.enable()
     print(json.dumps(result), flush=True)
     D.finalize()
 
