@@ -850,6 +850,7 @@ struct GemmLnArgs {
     int N, K;
     int64_t lda, ldw;
     uint16_t *y16, *y16lo;
+    int scenes;       // > 0: M = scenes * post_rows with whole 64-row tiles per scene -> scene-interleaved tile order
 };
 
 template <int NT16>
@@ -860,7 +861,16 @@ __global__ void __launch_bounds__(256, (NT16 <= 48 ? 2 : 1)) k_gemm_ln(GemmLnArg
     uint16_t *sw = reinterpret_cast<uint16_t *>(smem);          // [N][WROW]
     uint16_t *sa = sw + N * WROW;                                 // [64][WROW]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
-    const int64_t m0 = (int64_t)blockIdx.x * 64;
+    // Tile order.  The positional table (post_rows x N fp32: 805 MB at 512x512x768) is the largest operand and every scene
+    // re-reads all of it; walking the tiles scene-major streamed it from HBM once per scene.  Scene-interleaved order puts
+    // the `scenes` workgroups that share a table tile on the SAME XCD (block ids 8 apart) back to back, so the table
+    // leaves HBM once per step and the repeats are L2 hits.
+    int64_t m0 = (int64_t)blockIdx.x * 64;
+    if (g.scenes > 0) {
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int sc = k % g.scenes, pt = (k / g.scenes) * 8 + x;
+        m0 = ((int64_t)sc * (g.post_rows >> 6) + pt) * 64;
+    }
     const int nk = g.K / 32;
 
     f32x4 acc[NT16];
@@ -976,6 +986,175 @@ __global__ void __launch_bounds__(256, (NT16 <= 48 ? 2 : 1)) k_gemm_ln(GemmLnArg
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Row-streaming form of the same op for K = 64 (the 1x1 conv of the BEV token path), plain bf16 operands.
+// The tile kernel above is latency-bound: every thread walks 24 dependent {table load -> LDS transpose -> store} steps with
+// 8 waves per CU (1.4-1.6 ms for 4 x 512 x 512 rows, ~3x its HBM time).  Here
+//   * W (N x 64 bf16, <= 128 KiB) is staged into LDS ONCE per workgroup (swizzled 128-byte rows); after that
+//     one barrier the waves never synchronise again;
+//   * the product is computed TRANSPOSED (W rows are the MFMA A operand, 16 data rows the B operand, fetched straight
+//     from global): the C layout then gives each lane 4 output columns of ONE data row per tile, and with the column
+//     assignment n = 64 G + 16 g + 4 t + r (g = lane >> 4, t = tile of the group, r = register) a lane owns 16 CONSECUTIVE
+//     columns of its row per group of 4 tiles -- stores, table and gamma/beta reads are whole 16-byte vectors, no LDS
+//     transpose;
+//   * with K = 64 the product costs two MFMAs per tile, so LayerNorm is done in three passes that RECOMPUTE it
+//     (mean, centred variance, output): no N-wide accumulator;
+//   * a wave handles the same 16 table rows for up to SB scenes at once: the positional table (805 MB fp32 at
+//     512 x 512 x 768) is read from HBM exactly once per step, into registers, whatever the caches do.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LNR_WAVES = 12;      // 3 waves per SIMD: ~150 VGPRs (af 32 + table 16 + packed outputs 32 + fragments) without spilling
+template <int NG, int SB>
+__global__ void __launch_bounds__(LNR_WAVES * 64) k_gemm_ln_rows(GemmLnArgs g, int n_ptiles, int scenes, int64_t rows_per_scene) {
+    constexpr int N = NG * 64;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *sw = smem;                                         // [N][128 B], 16-byte chunk c of row n at (c ^ f(n)) * 16
+    float *sbias = reinterpret_cast<float *>(smem + N * 128), *sgam = sbias + N, *sbet = sgam + N;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g4 = lane >> 4, l15 = lane & 15;
+    // f(n) = bit1(n) | ((n >> 4) & 3) << 1: conflict-free for the A-operand ds_read_b128 below (rows 16 b + 4 t + r, b = l15 >> 2)
+    for (int e = tid; e < N * 8; e += LNR_WAVES * 64) {
+        const int row = e >> 3, ch = e & 7;
+        const uint4 v = *reinterpret_cast<const uint4 *>(g.w[0] + (int64_t)row * g.ldw + ch * 8);
+        const int f = ((row >> 1) & 1) | (((row >> 4) & 3) << 1);
+        *reinterpret_cast<uint4 *>(sw + row * 128 + ((ch ^ f) << 4)) = v;
+    }
+    for (int e = tid; e < N; e += LNR_WAVES * 64) {
+        sbias[e] = g.bias ? g.bias[e] : 0.f;
+        sgam[e] = g.gamma[e];
+        sbet[e] = g.beta ? g.beta[e] : 0.f;
+    }
+    __syncthreads();
+
+    const int fsw = ((l15 >> 1) & 1) | ((l15 >> 2) << 1);
+    const uint8_t *wrow = sw + (16 * (l15 >> 2) + (l15 & 3)) * 128;      // + (64 G + 4 t) * 128
+    const int wc0 = (g4 ^ fsw) << 4, wc1 = ((4 + g4) ^ fsw) << 4;        // k chunks g4 and 4 + g4 of the row
+    const int cofs = 16 * g4;                                            // first of this lane's 16 columns in a group
+    const float inv_n = 1.0f / (float)N;
+
+    for (int tile = blockIdx.x * LNR_WAVES + wid; tile < n_ptiles; tile += gridDim.x * LNR_WAVES) {
+        const int64_t p = (int64_t)tile * 16 + l15;                      // row inside a scene (= table row)
+        for (int s0 = 0; s0 < scenes; s0 += SB) {
+            // B operand: 16 data rows x 64 k per scene, straight from global (lane: row l15, k = 8 g4 .. +7 and 32 + 8 g4 ..)
+            bf16x8 af[SB][2];
+            int64_t rows[SB];
+#pragma unroll
+            for (int sc = 0; sc < SB; ++sc) {
+                int64_t r = (int64_t)(s0 + sc < scenes ? s0 + sc : scenes - 1) * rows_per_scene + p;
+                rows[sc] = r;
+                r = r < g.M ? r : g.M - 1;
+                const uint16_t *src = g.a[0] + r * g.lda + 8 * g4;
+                af[sc][0] = *reinterpret_cast<const bf16x8 *>(src);
+                af[sc][1] = *reinterpret_cast<const bf16x8 *>(src + 32);
+            }
+            // ---- pass 1: mean, pass 2: centred sum of squares (both recompute z = W a + bias) ----
+            float mean[SB], rstd[SB];
+#pragma unroll
+            for (int sc = 0; sc < SB; ++sc) mean[sc] = 0.f;
+#pragma unroll 1
+            for (int gt = 0; gt < NG * 4; ++gt) {
+                const int G = gt >> 2, t = gt & 3;
+                const uint8_t *wa = wrow + (64 * G + 4 * t) * 128;
+                const bf16x8 f0 = *reinterpret_cast<const bf16x8 *>(wa + wc0), f1 = *reinterpret_cast<const bf16x8 *>(wa + wc1);
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(sbias + 64 * G + cofs + 4 * t);
+#pragma unroll
+                for (int sc = 0; sc < SB; ++sc) {
+                    f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, af[sc][0], bv, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, af[sc][1], acc, 0, 0, 0);
+                    mean[sc] += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+                }
+            }
+#pragma unroll
+            for (int sc = 0; sc < SB; ++sc) {
+                mean[sc] += __shfl_xor(mean[sc], 16);
+                mean[sc] += __shfl_xor(mean[sc], 32);
+                mean[sc] *= inv_n;
+                rstd[sc] = 0.f;
+            }
+#pragma unroll 1
+            for (int gt = 0; gt < NG * 4; ++gt) {
+                const int G = gt >> 2, t = gt & 3;
+                const uint8_t *wa = wrow + (64 * G + 4 * t) * 128;
+                const bf16x8 f0 = *reinterpret_cast<const bf16x8 *>(wa + wc0), f1 = *reinterpret_cast<const bf16x8 *>(wa + wc1);
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(sbias + 64 * G + cofs + 4 * t);
+#pragma unroll
+                for (int sc = 0; sc < SB; ++sc) {
+                    f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, af[sc][0], bv, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, af[sc][1], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float d = acc[r] - mean[sc]; rstd[sc] = fmaf(d, d, rstd[sc]); }
+                }
+            }
+#pragma unroll
+            for (int sc = 0; sc < SB; ++sc) {
+                rstd[sc] += __shfl_xor(rstd[sc], 16);
+                rstd[sc] += __shfl_xor(rstd[sc], 32);
+                rstd[sc] = 1.0f / sqrtf(rstd[sc] * inv_n + g.eps);
+            }
+            // ---- pass 3: output, one 64-column group at a time; the table chunk is loaded once for all SB scenes ----
+#pragma unroll 1
+            for (int G = 0; G < NG; ++G) {
+                f32x4 pe[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pe[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (g.post) {
+                    const float *ps = g.post + (p % g.post_rows) * N + 64 * G + cofs;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pe[t] = *reinterpret_cast<const f32x4 *>(ps + 4 * t);
+                }
+                uint32_t out[SB][8];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const uint8_t *wa = wrow + (64 * G + 4 * t) * 128;
+                    const bf16x8 f0 = *reinterpret_cast<const bf16x8 *>(wa + wc0), f1 = *reinterpret_cast<const bf16x8 *>(wa + wc1);
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(sbias + 64 * G + cofs + 4 * t);
+                    const f32x4 gv = *reinterpret_cast<const f32x4 *>(sgam + 64 * G + cofs + 4 * t);
+                    const f32x4 be = *reinterpret_cast<const f32x4 *>(sbet + 64 * G + cofs + 4 * t);
+#pragma unroll
+                    for (int sc = 0; sc < SB; ++sc) {
+                        f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f0, af[sc][0], bv, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1, af[sc][1], acc, 0, 0, 0);
+                        float y[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = ((acc[r] - mean[sc]) * rstd[sc]) * gv[r] + be[r] + pe[t][r];
+                        out[sc][2 * t] = pack_bf16(y[0], y[1]);
+                        out[sc][2 * t + 1] = pack_bf16(y[2], y[3]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // keep the next tile's fragment / parameter reads from piling up (spills)
+                }
+#pragma unroll
+                for (int sc = 0; sc < SB; ++sc)
+                    if (s0 + sc < scenes && rows[sc] < g.M) {
+                        uint16_t *dst = g.y16 + rows[sc] * N + 64 * G + cofs;
+                        *reinterpret_cast<uint4 *>(dst) = make_uint4(out[sc][0], out[sc][1], out[sc][2], out[sc][3]);
+                        *reinterpret_cast<uint4 *>(dst + 8) = make_uint4(out[sc][4], out[sc][5], out[sc][6], out[sc][7]);
+                    }
+            }
+        }
+    }
+}
+
+template <int NG> int launch_gemm_ln_rows(const GemmLnArgs &g, hipStream_t st) {
+    constexpr int SB = 4;
+    const size_t lds = (size_t)NG * 64 * 128 + (size_t)3 * NG * 64 * sizeof(float);
+    static int ok = -1;
+    if (ok < 0) ok = hipFuncSetAttribute((const void *)k_gemm_ln_rows<NG, SB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); return LVQ_EUNSUPPORTED; }
+    int scenes = 1;
+    int64_t rps = g.M;
+    if (g.post && g.M > g.post_rows) { scenes = (int)(g.M / g.post_rows); rps = g.post_rows; }
+    const int64_t n_pt = lvq_cdiv(rps, 16);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const int64_t want = lvq_cdiv(n_pt, LNR_WAVES);
+    const unsigned grid = (unsigned)(want < n_cu ? want : n_cu);
+    hipLaunchKernelGGL((k_gemm_ln_rows<NG, SB>), dim3(grid), dim3(LNR_WAVES * 64), lds, st, g, (int)n_pt, scenes, rps);
+    return lvq_launch_status();
 }
 
 template <int NT16> int launch_gemm_ln(const GemmLnArgs &g, hipStream_t st) {
@@ -1158,7 +1337,24 @@ extern "C" int lvq_gemm_ln_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const l
     g.a[0] = a; g.w[0] = w; g.a[1] = a; g.w[1] = w_lo; g.a[2] = a_lo; g.w[2] = w;
     g.bias = bias; g.gamma = gamma; g.beta = beta; g.post = post_add; g.post_rows = post_rows; g.eps = eps;
     g.M = m; g.N = n; g.K = k; g.lda = lda; g.ldw = ldw; g.y16 = y_bf16; g.y16lo = y_lo;
+    g.scenes = 0;
+    if (post_add && post_rows % 512 == 0 && m % post_rows == 0 && m / post_rows > 1 && m / post_rows <= 4096)
+        g.scenes = (int)(m / post_rows);            // whole tiles per scene, tiles-per-scene a multiple of the 8 XCDs
     hipStream_t st = lvq_s(stream);
+    // K = 64, plain bf16, table rows aligned to scenes: the row-streaming kernel (W resident in LDS, table read once)
+    if (g.nseg == 1 && k == 64 && n % 64 == 0 && n <= 1024 && lvq_cdiv(m, 16) <= 0x7fffffff && getenv("LVQ_GEMM_LN_TILES") == nullptr &&
+        (!post_add || m <= post_rows || (post_rows % 16 == 0 && m % post_rows == 0))) {
+        int rc = LVQ_EUNSUPPORTED;
+        switch (n) {
+            case 256: rc = launch_gemm_ln_rows<4>(g, st); break;
+            case 512: rc = launch_gemm_ln_rows<8>(g, st); break;
+            case 768: rc = launch_gemm_ln_rows<12>(g, st); break;
+            case 896: rc = launch_gemm_ln_rows<14>(g, st); break;
+            case 1024: rc = launch_gemm_ln_rows<16>(g, st); break;
+            default: break;
+        }
+        if (rc != LVQ_EUNSUPPORTED) return rc;
+    }
     switch (n) {   // row-complete tiles: one instantiation per supported d_model
         case 256: return launch_gemm_ln<16>(g, st);
         case 512: return launch_gemm_ln<32>(g, st);

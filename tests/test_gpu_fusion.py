@@ -128,6 +128,30 @@ def test_gemm_ln_fused(m, n, k, split):
     assert err < (2.0 ** -8 * ref.abs().max().item() if not split else 3e-4), err      # plain mode: output rounded to bf16 (one ulp)
 
 
+@pytest.mark.parametrize("scenes,post_rows,n", [(3, 1024, 768), (2, 512, 768), (5, 1536, 768), (1, 1000, 768), (6, 48, 256),
+                                                (1, 333, 1024), (9, 80, 896), (4, 2000, 512)])
+def test_gemm_ln_scene_interleaved(scenes, post_rows, n):
+    """K = 64 with M = scenes x post_rows: the row-streaming kernel (k_gemm_ln_rows) handles the same table rows of up to 4
+    scenes per wave (table read once); ragged last 16-row tiles, scene batches (9 = 4 + 4 + 1) and every supported N."""
+    o = ops()
+    m, k = scenes * post_rows, 64
+    a = bf_round(torch.from_numpy(synth.randn((m, k), 51))).to(DEV)
+    w = bf_round(torch.from_numpy(synth.randn((n, k), 52, 0.2))).to(DEV)
+    bias = torch.from_numpy(synth.randn((n,), 53)).to(DEV)
+    gam = torch.from_numpy(synth.randn((n,), 54)).to(DEV) + 1.0
+    bet = torch.from_numpy(synth.randn((n,), 55)).to(DEV)
+    post = torch.from_numpy(synth.randn((post_rows, n), 56)).to(DEV)
+    y = o.linear_ln(o.cast(a, False), o.cast(w, False), bias, gam, bet, 1e-5, post=post)
+    z = a.double().cpu() @ w.double().cpu().t() + bias.double().cpu()
+    ref = torch.nn.functional.layer_norm(z, (n,), gam.double().cpu(), bet.double().cpu(), 1e-5) + post.double().cpu()[torch.arange(m) % post_rows]
+    err = (o.to_f32(y).double().cpu() - ref).abs().max().item()
+    assert err < 2.0 ** -8 * ref.abs().max().item(), err
+    # no table at all (m rows, ragged)
+    y2 = o.linear_ln(o.cast(a[:m - 5], False), o.cast(w, False), bias, gam, bet, 1e-5)
+    ref2 = torch.nn.functional.layer_norm(z[:m - 5], (n,), gam.double().cpu(), bet.double().cpu(), 1e-5)
+    assert (o.to_f32(y2).double().cpu() - ref2).abs().max().item() < 2.0 ** -8 * ref2.abs().max().item()
+
+
 ATT_CASES = [
     # B, H, Hkv, nq, nkv, dh, bias, causal
     (1, 2, 2, 16, 64, 64, False, False),
