@@ -125,75 +125,67 @@ bool launch_norm_vec(const float *x, const float *add, int add_rows, int add_gro
     return false;
 }
 
-// depthwise 3x3 (pad 1) + GELU, NCHW fp32 -> token-major bf16.  Block = 64 channels x 4 rows x 32 pixels: the 6 x 34
-// input halo is loaded once (1.6x re-read instead of 3x), every thread slides a 3-row window down 4 output rows for
-// 8 channels, and the [pixel][channel] outputs leave through LDS as whole 128-byte token rows (16-byte stores).
-constexpr int DW_C = 64, DW_RY = 2, DW_PX = 32;
+// depthwise 3x3 (pad 1) + GELU, NCHW fp32 -> token-major bf16.  Block = 64 channels x 4 rows x 64 pixels, one pixel
+// column per lane: a wave takes 16 of the channels one after the other and slides a 3-row register window down the
+// 6 input rows, reading each row as three coalesced 256-byte loads (x-1, x, x+1: the overlap is an L1 hit, HBM sees the
+// halo rows only -- 1.5x instead of the 2.1x of an LDS-staged 4 x 34 tile, and no per-element index arithmetic).  The
+// [pixel][channel] outputs leave through LDS as whole 128-byte token rows (16-byte stores); the lo plane only in bf16x3.
+constexpr int DW_C = 64, DW_RY = 4, DW_PX = 64;
+
+template <bool LO>
 __global__ void __launch_bounds__(256) k_dwconv3x3_gelu(const float *__restrict__ bev, const float *__restrict__ w9,
                                                         const float *__restrict__ bias, int C, int H, int W,
                                                         uint16_t *__restrict__ thi, uint16_t *__restrict__ tlo) {
-    __shared__ float tile[DW_C][DW_RY + 2][DW_PX + 4];                       // 64 x 4 x 36 floats = 36 KB (+ 2 x 9 KB out: 2-3 blocks/CU)
-    __shared__ __attribute__((aligned(16))) uint16_t oh[DW_RY][DW_PX][DW_C + 8];   // +16 B pad per pixel row
-    __shared__ __attribute__((aligned(16))) uint16_t ol[DW_RY][DW_PX][DW_C + 8];
+    __shared__ __attribute__((aligned(16))) uint16_t oh[DW_RY][DW_PX][DW_C + 8];   // +16 B pad per pixel row (36 KB)
+    __shared__ __attribute__((aligned(16))) uint16_t ol[LO ? DW_RY : 1][LO ? DW_PX : 1][DW_C + 8];
     const int x0 = blockIdx.x * DW_PX, y0 = blockIdx.y * DW_RY;
     const int cblocks = (C + DW_C - 1) / DW_C;
     const int b = blockIdx.z / cblocks, c0 = (blockIdx.z % cblocks) * DW_C;
-    const int tid = threadIdx.x;
-    constexpr int ROWE = DW_PX + 2, PLANE = (DW_RY + 2) * ROWE;              // 34, 204
-    // 8 independent loads in flight per thread before the LDS writes (a load->store loop waits one HBM latency per element)
-    for (int e0 = tid; e0 < DW_C * PLANE; e0 += 256 * 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * 256;
-            const int c = e / PLANE, rem = e - c * PLANE, r = rem / ROWE, xx = rem - r * ROWE;
-            const int gx = x0 + xx - 1, gy = y0 + r - 1, gc = c0 + c;
-            v[u] = 0.f;
-            if (e < DW_C * PLANE && gc < C && gx >= 0 && gx < W && gy >= 0 && gy < H) v[u] = bev[(((int64_t)b * C + gc) * H + gy) * W + gx];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = e0 + u * 256;
-            const int c = e / PLANE, rem = e - c * PLANE, r = rem / ROWE, xx = rem - r * ROWE;
-            if (e < DW_C * PLANE) tile[c][r][xx] = v[u];
-        }
-    }
-    __syncthreads();
-    const int xx = tid & 31, cg = tid >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int gx = x0 + lane;
+    const bool in_m = gx < W, in_l = gx - 1 >= 0 && gx - 1 < W, in_r = gx + 1 < W;
 #pragma unroll 1
-    for (int i = 0; i < DW_C / 8; ++i) {
-        const int c = cg * 8 + i, gc = c0 + c;
-        float wk[9], bs = 0.f;
+    for (int ci = 0; ci < DW_C / 4; ++ci) {
+        const int c = wid * (DW_C / 4) + ci, gc = c0 + c;
+        if (gc >= C) break;                                   // wave-uniform
+        float wk[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wk[k] = gc < C ? w9[gc * 9 + k] : 0.f;
-        if (gc < C && bias) bs = bias[gc];
-        float win[DW_RY + 2][3];
+        for (int k = 0; k < 9; ++k) wk[k] = w9[gc * 9 + k];
+        const float bs = bias ? bias[gc] : 0.f;
+        const float *plane = bev + ((int64_t)b * C + gc) * H * W;
+        float win[3][3];
 #pragma unroll
-        for (int r = 0; r < DW_RY + 2; ++r)
+        for (int r = 0; r < DW_RY + 2; ++r) {
+            const int gy = y0 + r - 1;
+            const bool rin = gy >= 0 && gy < H;
+            const float *rowp = plane + (int64_t)(rin ? gy : 0) * W + gx;
+            float *wr = win[r % 3];
+            wr[0] = (rin && in_l) ? rowp[-1] : 0.f;
+            wr[1] = (rin && in_m) ? rowp[0] : 0.f;
+            wr[2] = (rin && in_r) ? rowp[1] : 0.f;
+            if (r >= 2) {
+                const int ry = r - 2;
+                float acc = bs;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) win[r][k] = tile[c][r][xx + k];
+                for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-        for (int ry = 0; ry < DW_RY; ++ry) {
-            float acc = bs;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) acc = fmaf(win[ry + r][k], wk[r * 3 + k], acc);
-            acc = gelu_erf(acc);
-            const uint16_t h = f32_to_bf16(acc);
-            oh[ry][xx][c] = h;
-            ol[ry][xx][c] = f32_to_bf16(acc - bf16_to_f32(h));
+                    for (int k = 0; k < 3; ++k) acc = fmaf(win[(ry + rr) % 3][k], wk[rr * 3 + k], acc);
+                acc = gelu_erf(acc);
+                const uint16_t h = f32_to_bf16(acc);
+                oh[ry][lane][c] = h;
+                if (LO) ol[ry][lane][c] = f32_to_bf16(acc - bf16_to_f32(h));
+            }
         }
     }
     __syncthreads();
     const int nc = (C - c0) < DW_C ? (C - c0) : DW_C;            // channels of this block (multiple of 8)
     for (int e = tid; e < DW_RY * DW_PX * (DW_C / 8); e += 256) {
-        const int ch = e & 7, px = (e >> 3) & (DW_PX - 1), ry = e >> 8;   // 8 chunks x 32 pixels = 256 per output row
-        const int gx = x0 + px, gy = y0 + ry;
-        if (gx < W && gy < H && ch * 8 < nc) {
-            const int64_t o = ((int64_t)b * H * W + (int64_t)gy * W + gx) * C + c0 + ch * 8;
+        const int ch = e & 7, px = (e >> 3) & (DW_PX - 1), ry = e / (8 * DW_PX);
+        const int ox = x0 + px, gy = y0 + ry;
+        if (ox < W && gy < H && ch * 8 < nc) {
+            const int64_t o = ((int64_t)b * H * W + (int64_t)gy * W + ox) * C + c0 + ch * 8;
             *reinterpret_cast<uint4 *>(thi + o) = *reinterpret_cast<const uint4 *>(&oh[ry][px][ch * 8]);
-            if (tlo) *reinterpret_cast<uint4 *>(tlo + o) = *reinterpret_cast<const uint4 *>(&ol[ry][px][ch * 8]);
+            if (LO) *reinterpret_cast<uint4 *>(tlo + o) = *reinterpret_cast<const uint4 *>(&ol[ry][px][ch * 8]);
         }
     }
 }
@@ -305,7 +297,8 @@ extern "C" int lvq_dwconv3x3_gelu(const float *bev, const float *w9, const float
     const int cblocks = (ch + DW_C - 1) / DW_C;
     if ((int64_t)batch * cblocks > 65535 || lvq_cdiv(h, DW_RY) > 65535) return LVQ_EUNSUPPORTED;
     dim3 grid((unsigned)lvq_cdiv(w, DW_PX), (unsigned)lvq_cdiv(h, DW_RY), (unsigned)(batch * cblocks));
-    hipLaunchKernelGGL(k_dwconv3x3_gelu, grid, dim3(256), 0, lvq_s(stream), bev, w9, bias, ch, h, w, tokens_hi, tokens_lo);
+    if (tokens_lo) hipLaunchKernelGGL(k_dwconv3x3_gelu<true>, grid, dim3(256), 0, lvq_s(stream), bev, w9, bias, ch, h, w, tokens_hi, tokens_lo);
+    else           hipLaunchKernelGGL(k_dwconv3x3_gelu<false>, grid, dim3(256), 0, lvq_s(stream), bev, w9, bias, ch, h, w, tokens_hi, tokens_lo);
     return lvq_launch_status();
 }
 

@@ -101,6 +101,17 @@ def bench_projln():
         print(f"proj+LN+PE (M={m}, N={n}, K={k}) {'x3' if split else 'bf16'}: fused {t:.3f} ms, unfused {t2:.3f} ms")
 
 
+def bench_dwconv():
+    for S, C, H, W in [(4, 64, 512, 512)]:
+        x = torch.randn(S, C, H, W, device=DEV)
+        w9 = torch.randn(C, 9, device=DEV) * 0.3
+        b = torch.randn(C, device=DEV)
+        for split in (False, True):
+            t, _ = timeit(lambda: ops.dwconv3x3_gelu(x, w9, b, split), iters=10)
+            by = S * C * H * W * (4 + (4 if split else 2))
+            print(f"dwconv3x3+gelu S={S} C={C} {H}x{W} {'x3' if split else 'bf16'}: {t * 1e3:.1f} us  {by / t / 1e6:.0f} GB/s algorithmic")
+
+
 def bench_vox():
     rng = list(synth.PC_RANGE_NUSC)
     for S, n, vs, T, mv, what in [(8, 65536, synth.VOXEL_01, 10, 160000, "cfg-3 0.1m"), (1, 32768, synth.VOXEL_01, 10, 60000, "cfg-2 0.1m"),
@@ -153,4 +164,4 @@ if __name__ == "__main__":
     for w in which:
         print(f"==== {w} ====")
         {"gemm": bench_gemm, "attn": bench_attn, "norm": bench_norm, "vox": bench_vox, "attn1": bench_attn_one,
-         "gemm1": bench_gemm_one, "projln": bench_projln}[w]()
+         "gemm1": bench_gemm_one, "projln": bench_projln, "dwconv": bench_dwconv}[w]()
