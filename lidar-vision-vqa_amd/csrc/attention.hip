@@ -471,6 +471,288 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_attn32: head_dim 64, plain bf16, long K/V stream, no bias / mask, Nkv % 64 == 0 -- on 32x32x16 MFMAs.
+// Why a second formulation: the 16x16x32 loop above is bound by the SIMD's vector ISSUE port, not by the matrix pipe.  An
+// MFMA holds the port for 8 cycles whatever its shape, so a 16-cycle 16x16x32 leaves 8 free cycles (two VALU slots) and a
+// 32-cycle 32x32x16 leaves 24 (six slots) for the same FLOPs per cycle; and with 32 queries per wave each K / V fragment
+// read from LDS serves twice the queries, the row maximum needs one cross-lane step per 32 keys instead of two per 16.
+// Layout (S^T = K Q^T as before): A = K rows (lane: key l&31, dh 16 ks + 8 hi + j, hi = lane >> 5), B = Q^T (lane: query
+// l&31, same dh) -> C: lane (query, hi) holds keys 8 (i>>2) + 4 hi + (i&3), i = 0..15, of each 32-key block.  Registers
+// 8 s .. 8 s + 7 of a block are therefore exactly the B operand of O^T += V^T P^T for the 16-key step s under the key
+// permutation  k-index 8 hi + j  <->  key 16 s + 8 (j>>2) + 4 hi + (j&3),  and the A operand V^T follows the same permutation
+// with two ds_read_b64_tr_b16 (rows 16 s + 4 hi + 0..3 and + 8) -- nothing is shuffled between the two products.
+// LDS rows are unpadded 128-byte rows, chunk index XORed by f(row) = bit1(row) << 2 | (row >> 2) & 3: conflict-free for the
+// ds_read_b128 K reads (16 distinct rows per 16-lane group) and for the transposed V reads (4 rows x 64 B per half wave).
+// The row sum is a VALU add per score (a ones-row would cost a whole 32-row MFMA); deferred rescale as in k_attn.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ds_read_b64_tr_b16 as opaque asm: the builtin carries no alias information, so behind an LDS-DMA (global_load_lds) the
+// compiler's waitcnt pass puts s_waitcnt vmcnt(0) in front of it -- i.e. it waits for the K/V request that was JUST made for two
+// tiles ahead, and the stream runs at one memory round trip per tile.  The asm form is invisible to that pass; the consumer
+// waits on lgkmcnt itself (lds_tr_wait) -- hardware counters are in order, so the compiler's own counted waits stay sufficient.
+__device__ __forceinline__ bf16x4 lds_tr_read(uint32_t lds_byte_addr) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_byte_addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_tr_wait(bf16x4 &a, bf16x4 &b, bf16x4 &c, bf16x4 &d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+// same, leaving the four newest LDS reads in flight (the next step's fragments)
+__device__ __forceinline__ void lds_tr_wait4(bf16x4 &a, bf16x4 &b, bf16x4 &c, bf16x4 &d) {
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
+    constexpr int DH = 64, KROW = 64, CH = 8, NT = NW * 64;
+    constexpr int NLD = (KVB * CH + NT - 1) / NT;
+    constexpr int TILE_E = 2 * KVB * KROW;                     // K + V of one stage (bf16 elements)
+    constexpr float THR = 6.0f;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    const int grp = blockIdx.x / a.nqt, qtile = blockIdx.x - grp * a.nqt;
+    const int sp = grp % a.nsplit, h = (grp / a.nsplit) % a.H, b = grp / (a.nsplit * a.H);
+    const int hk = h / (a.H / a.Hkv);
+    const int q0 = qtile * (NW * 32) + wid * 32;
+    const int qi = q0 + l31;
+    const float cexp0 = a.scale * 1.4426950408889634f;
+
+    // Q^T fragments, pre-multiplied by scale * log2(e): lane supplies Q[qi][16 ks + 8 hi .. +7]
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (qi < a.Nq) v = *reinterpret_cast<const uint4 *>(a.q + (int64_t)b * a.q_bs + (int64_t)qi * a.ldq + (int64_t)h * a.q_hs + 16 * ks + 8 * hi);
+        uint32_t *w = reinterpret_cast<uint32_t *>(&v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = pack_bf16(__uint_as_float(w[e] << 16) * cexp0, __uint_as_float(w[e] & 0xffff0000u) * cexp0);
+        qf[ks] = *reinterpret_cast<bf16x8 *>(&v);
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+    float mref = 0.f, lsum = 0.f;
+    bool fresh = true;
+
+    const int n_tiles = a.Nkv / KVB;
+    const int tps = (n_tiles + a.nsplit - 1) / a.nsplit;
+    const int t0 = sp * tps;
+    const int t1 = t0 + tps < n_tiles ? t0 + tps : n_tiles;
+
+    // ---- K/V staging by LDS-DMA (global_load_lds, 16 B per lane, no VGPRs -- registers are what limits occupancy here).
+    // A tile's K and V are 8 + 8 pieces of 8 rows x 128 B; wave w moves pieces w, w + NW, ...  The DMA writes lane-linear
+    // (lane 8 r + c -> row r, chunk position c of the piece), so position c of row `row` is filled with SOURCE chunk c ^ f(row).
+    // Three LDS slots: tile t+2 is requested at the top of tile t into the slot tile t-1 just left; tile t+1 has landed when a
+    // counted vmcnt leaves exactly this wave's newest request in flight.
+    const int wave_b = __builtin_amdgcn_readfirstlane(b), wave_hk = __builtin_amdgcn_readfirstlane(hk);
+    const uint16_t *kbase = a.k + (int64_t)wave_b * a.k_bs + (int64_t)wave_hk * a.k_hs;
+    const uint16_t *vbase = a.v + (int64_t)wave_b * a.v_bs + (int64_t)wave_hk * a.v_hs;
+    const int r8 = lane >> 3, pch = lane & 7;
+    constexpr int NPC = (16 + NW - 1) / NW;                    // DMA pieces per wave per tile (K pieces 0..7, V pieces 8..15)
+    auto dma = [&](int t, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) {
+            const int pc = wid + NW * j;                       // wave-uniform
+            if (pc < 16) {
+                const int isv = pc >> 3, piece = pc & 7, row = piece * 8 + r8;
+                const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+                const uint16_t *src = (isv ? vbase + ((int64_t)t * KVB + row) * a.ldv : kbase + ((int64_t)t * KVB + row) * a.ldk) + ((pch ^ f) << 3);
+                uint16_t *dst = smem + slot * TILE_E + isv * (KVB * KROW) + piece * 512;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            }
+        }
+    };
+    const int my_pieces = (16 - wid + NW - 1) / NW;            // this wave's DMA instructions per tile
+
+    // per-lane LDS offsets (elements).  K A-operand: row l31 (+32 kb), chunk 2 ks + hi.
+    const int fk = (((l31 >> 1) & 1) << 2) | ((l31 >> 2) & 3);           // f(row) of rows l31 and l31 + 32
+    // V^T A-operand through the transposing read: this lane ADDRESSES row 16 s + 4 hi + q' (+8) and columns
+    // 32 dblk + 16 (g16 & 1) + 4 p .. + 3 (q' = (lane & 15) >> 2, p = lane & 3, g16 = lane >> 4) and RECEIVES column
+    // 32 dblk + (lane & 31) of the block's four rows
+    const int qp = (lane & 15) >> 2, pp = lane & 3, gh = (lane >> 4) & 1;
+    auto v_off = [&](int row, int dblk) __attribute__((always_inline)) {   // row inside the 64-row tile
+        const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+        const int chunk = dblk * 4 + gh * 2 + (pp >> 1);
+        return row * KROW + ((chunk ^ f) << 3) + 4 * (pp & 1);
+    };
+
+    auto scores = [&](const uint16_t *Ks, float sinit, f32x16 (&sc)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sc[kb][i] = sinit;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + (kb * 32 + l31) * KROW + (((2 * ks + hi) ^ fk) << 3));
+                sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
+            }
+        }
+    };
+    // row maximum over the tile's 64 keys: 32 in this lane, 32 in lane ^ 32
+    auto row_max = [&](const f32x16 (&sc)[2]) __attribute__((always_inline)) {
+        float tmax = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
+#pragma unroll
+        for (int i = 4; i < 16; i += 2) tmax = fmaxf(fmaxf(tmax, sc[0][i]), sc[0][i + 1]);
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) tmax = fmaxf(fmaxf(tmax, sc[1][i]), sc[1][i + 1]);
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+    // P = exp2(scores), row sums, O^T += V^T P^T.  Per 32-key block: the eight transposed V reads of its two 16-key steps are issued
+    // first (they land under the 16 exps), then each step waits only for its own four.
+    auto finish = [&](const uint16_t *Vs, const f32x16 (&sc)[2]) __attribute__((always_inline)) {
+        const uint32_t vb = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint16_t *)Vs);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int r0 = kb * 32 + 4 * hi + qp;
+            bf16x4 a00 = lds_tr_read(vb + 2 * v_off(r0, 0)), a01 = lds_tr_read(vb + 2 * v_off(r0 + 8, 0));
+            bf16x4 a10 = lds_tr_read(vb + 2 * v_off(r0, 1)), a11 = lds_tr_read(vb + 2 * v_off(r0 + 8, 1));
+            bf16x4 b00 = lds_tr_read(vb + 2 * v_off(r0 + 16, 0)), b01 = lds_tr_read(vb + 2 * v_off(r0 + 24, 0));
+            bf16x4 b10 = lds_tr_read(vb + 2 * v_off(r0 + 16, 1)), b11 = lds_tr_read(vb + 2 * v_off(r0 + 24, 1));
+            float p[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p[i] = fast_exp2(sc[kb][i]);
+            const float s0 = (p[0] + p[1]) + (p[2] + p[3]), s1 = (p[4] + p[5]) + (p[6] + p[7]);
+            const float s2 = (p[8] + p[9]) + (p[10] + p[11]), s3 = (p[12] + p[13]) + (p[14] + p[15]);
+            lsum += (s0 + s1) + (s2 + s3);
+            uint4 u0 = make_uint4(pack_bf16(p[0], p[1]), pack_bf16(p[2], p[3]), pack_bf16(p[4], p[5]), pack_bf16(p[6], p[7]));
+            uint4 u1 = make_uint4(pack_bf16(p[8], p[9]), pack_bf16(p[10], p[11]), pack_bf16(p[12], p[13]), pack_bf16(p[14], p[15]));
+            const bf16x8 pf0 = *reinterpret_cast<bf16x8 *>(&u0), pf1 = *reinterpret_cast<bf16x8 *>(&u1);
+            lds_tr_wait4(a00, a01, a10, a11);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(a00, a01, 0, 1, 2, 3, 4, 5, 6, 7), pf0, o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(a10, a11, 0, 1, 2, 3, 4, 5, 6, 7), pf0, o[1], 0, 0, 0);
+            lds_tr_wait(b00, b01, b10, b11);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(b00, b01, 0, 1, 2, 3, 4, 5, 6, 7), pf1, o[0], 0, 0, 0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(b10, b11, 0, 1, 2, 3, 4, 5, 6, 7), pf1, o[1], 0, 0, 0);
+        }
+    };
+
+    // DMA bookkeeping shared by the three loop forms below
+    int slot = 0;
+    auto pre = [&](int t) __attribute__((always_inline)) {
+        const int s2 = slot == 0 ? 2 : slot - 1;               // (slot + 2) % 3: the slot tile t-1 left at the last barrier
+        if (t + 2 < t1) dma(t + 2, s2);
+    };
+    auto post = [&](int t) __attribute__((always_inline)) {
+        // tile t+1 landed; this wave's request for tile t+2 (if any) stays in flight across the barrier
+        if (t + 2 < t1) {
+            if (my_pieces == NPC) __builtin_amdgcn_s_waitcnt((NPC & 15) | 0x70 | ((NPC >> 4) << 14));
+            else                  __builtin_amdgcn_s_waitcnt(((NPC - 1) & 15) | 0x70);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0070);
+        }
+        __builtin_amdgcn_s_barrier();      // raw: __syncthreads() would drain vmcnt(0), i.e. wait for the request just made
+        slot = slot == 2 ? 0 : slot + 1;
+    };
+
+    // The online-softmax reference mref is set by the first tile and then never moved: fp32 O / l and bf16 P keep their relative
+    // precision whatever the exponent, so the only hazard is overflow when a later score exceeds the first tile's maximum by
+    // ~2^100 -- which is detected at the end (row sum above 2^100 or not finite) and answered by running the stream again in the
+    // classic form (maximum tracked and O rescaled every tile).  The steady-state loop therefore has no row maximum, no branch
+    // and no rescale: a rescale inside it, even behind a never-taken branch, made the compiler copy the 32 accumulator
+    // registers every tile, and the 17-step v_max3 chain sat between the score MFMAs and the first exp.
+    uint32_t *redo_flag = reinterpret_cast<uint32_t *>(smem + 3 * TILE_E);
+    auto stream = [&](auto slow_tag) __attribute__((always_inline)) {
+        constexpr bool SLOW = decltype(slow_tag)::value;
+        slot = 0;
+        if (t0 < t1) dma(t0, 0);
+        if (t0 + 1 < t1) dma(t0 + 1, 1);
+        if (t0 + 1 < t1) {                                     // tile t0 landed, tile t0+1 may still fly
+            if (my_pieces == NPC) __builtin_amdgcn_s_waitcnt((NPC & 15) | 0x70 | ((NPC >> 4) << 14));
+            else                  __builtin_amdgcn_s_waitcnt(((NPC - 1) & 15) | 0x70);
+        } else {
+            __builtin_amdgcn_s_waitcnt(0x0070);
+        }
+        __builtin_amdgcn_s_barrier();
+        int t = t0;
+        if (t < t1) {                                          // first tile: absolute scores set the reference
+            f32x16 sc[2];
+            pre(t);
+            scores(smem, 0.f, sc);
+            mref = row_max(sc);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sc[kb][i] -= mref;
+            finish(smem + KVB * KROW, sc);
+            post(t);
+            fresh = false;
+            ++t;
+        }
+        for (; t < t1; ++t) {
+            f32x16 sc[2];
+            pre(t);
+            scores(smem + slot * TILE_E, -mref, sc);
+            if (SLOW) {
+                const float delta = fmaxf(row_max(sc), 0.f);
+                if (__any(delta > 0.f)) {
+                    const float al = fast_exp2(-delta);
+                    mref += delta;
+                    lsum *= al;
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) sc[kb][i] -= delta;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) o[d][i] *= al;
+                }
+            }
+            finish(smem + slot * TILE_E + KVB * KROW, sc);
+            post(t);
+        }
+    };
+    if (tid == 0) *redo_flag = 0;
+    stream(std::false_type{});
+    {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+        const float ltot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        if (!(ltot < 1.2676506e30f)) *redo_flag = 1;           // 2^100; also catches inf / NaN
+    }
+    __syncthreads();
+    if (*redo_flag) {                                          // workgroup-uniform
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+        lsum = 0.f; mref = 0.f; fresh = true;
+        stream(std::true_type{});
+    }
+
+    // ---- write back: lane (query, hi) holds O[qi][32 dblk + 8 (i>>2) + 4 hi + (i&3)]; the row sum is split over hi ----
+    {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
+        lsum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+    if (qi >= a.Nq) return;
+    if (a.nsplit > 1) {
+        float *pr = a.part + ((((int64_t)b * a.H + h) * a.nsplit + sp) * a.Nq + qi) * (a.dh + 2);
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4)
+                *reinterpret_cast<f32x4 *>(pr + 32 * d + 8 * i4 + 4 * hi) = f32x4{o[d][4 * i4], o[d][4 * i4 + 1], o[d][4 * i4 + 2], o[d][4 * i4 + 3]};
+        if (hi == 0) { pr[a.dh] = fresh ? -INFINITY : mref; pr[a.dh + 1] = lsum; }
+        return;
+    }
+    const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+    uint16_t *dst = a.o + (int64_t)b * a.o_bs + (int64_t)qi * a.ldo + (int64_t)h * a.o_hs;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) {
+            const uint2 hv = make_uint2(pack_bf16(o[d][4 * i4] * inv, o[d][4 * i4 + 1] * inv), pack_bf16(o[d][4 * i4 + 2] * inv, o[d][4 * i4 + 3] * inv));
+            *reinterpret_cast<uint2 *>(dst + 32 * d + 8 * i4 + 4 * hi) = hv;
+        }
+}
+
 // merge the KV splits: out = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s
 __global__ void __launch_bounds__(256) k_attn_combine(AttnArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -509,9 +791,31 @@ __global__ void __launch_bounds__(256) k_attn_combine(AttnArgs a) {
 }
 
 // launch geometry shared by lvq_attention_workspace_bytes and lvq_attention_bf16
-struct AttnPlan { int qt, nw, nqt, nsplit; };
-AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split) {
+struct AttnPlan { int qt, nw, nqt, nsplit, k32; };
+// k_attn32 geometry (0 = not applicable): 32 queries per wave, 6 or 4 waves, at most 1/8 of the query slots padding
+int plan_k32_waves(int nq, int nkv, int dh, bool split) {
+    if (split || dh != 64 || nkv < 4096 || (nkv % KVB) != 0 || getenv("LVQ_ATTN_NO32") != nullptr) return 0;
+    for (int nw : {6, 4}) {
+        const int64_t tile = 32 * nw, padded = (nq + tile - 1) / tile * tile;
+        if ((padded - nq) * 8 <= nq) return nw;
+    }
+    return 0;
+}
+AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, bool allow32 = false) {
     AttnPlan p;
+    p.k32 = allow32 ? plan_k32_waves(nq, nkv, dh, split) : 0;
+    if (p.k32) {
+        p.qt = 2; p.nw = p.k32;
+        p.nqt = (nq + 32 * p.nw - 1) / (32 * p.nw);
+        const int64_t base = (int64_t)p.nqt * n_heads * batch;
+        const int n_tiles = nkv / KVB;
+        int ns = (int)((4096 + base - 1) / base);
+        if (ns > n_tiles / 8) ns = n_tiles / 8;
+        if (ns < 1) ns = 1;
+        if (ns > 64) ns = 64;
+        p.nsplit = ns;
+        return p;
+    }
     const int dhp = (dh + 31) / 32 * 32;
     int qmax = (dhp <= 64 && !split) ? 4 : 2;
     if (dhp > 64 && split) qmax = 1;
@@ -632,9 +936,11 @@ __global__ void __launch_bounds__(256) k_transpose_bf16(const uint16_t *__restri
 
 extern "C" size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, int nkv, int dh, int precision) {
     if (dh <= 128 && (dh & 15) == 0) {              // fused kernel: workspace only for the KV-split partials
-        AttnPlan p = plan_attn(batch, n_heads, nq, nkv, dh, precision == 3);
-        if (p.nsplit == 1) return 256;
-        return lvq_align((size_t)batch * n_heads * p.nsplit * nq * (dh + 2) * sizeof(float)) + 256;
+        const AttnPlan p = plan_attn(batch, n_heads, nq, nkv, dh, precision == 3);
+        const AttnPlan p32 = plan_attn(batch, n_heads, nq, nkv, dh, precision == 3, true);   // chosen when there is no bias / mask
+        const int ns = p.nsplit > p32.nsplit ? p.nsplit : p32.nsplit;
+        if (ns == 1) return 256;
+        return lvq_align((size_t)batch * n_heads * ns * nq * (dh + 2) * sizeof(float)) + 256;
     }
     const int64_t nkp = (nkv + 7) / 8 * 8;
     const int ns = precision == 3 ? 2 : 1;
@@ -675,12 +981,24 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
         a.v_bs = v_bstride; a.ldv = ldv; a.v_hs = v_hstride; a.o_bs = o_bstride; a.ldo = ldo; a.o_hs = o_hstride;
         a.scale = scale; a.causal = causal; a.o = o; a.ol = o_lo;
         const int dhp = (dh + 31) / 32 * 32;
-        const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, split);
+        const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, split, bias == nullptr && !causal && o_lo == nullptr);
         a.nsplit = pl.nsplit; a.nqt = pl.nqt; a.part = nullptr;
         if (pl.nsplit > 1) {
             LvqArena arena(ws, ws_bytes);
             a.part = arena.take<float>((size_t)batch * n_heads * pl.nsplit * nq * (dh + 2));
             if (!arena.ok) return LVQ_EWORKSPACE;
+        }
+        if (pl.k32) {
+            const size_t lds = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16;  // three K+V slots + the redo flag
+            const int64_t nwg = (int64_t)a.B * a.H * a.nsplit * a.nqt;
+            if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
+            if (pl.k32 == 6) hipLaunchKernelGGL(k_attn32<6>, dim3((unsigned)nwg), dim3(384), lds, st, a);
+            else             hipLaunchKernelGGL(k_attn32<4>, dim3((unsigned)nwg), dim3(256), lds, st, a);
+            if (a.nsplit > 1) {
+                const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
+                hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
+            }
+            return lvq_launch_status();
         }
         if (!split) {
             switch (dhp) {

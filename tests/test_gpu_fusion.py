@@ -166,6 +166,12 @@ ATT_CASES = [
     (1, 2, 2, 24, 100, 448, False, False),      # split path (reference default vat_heads=2, d=896)
     (1, 2, 2, 12, 60, 1024, False, False),      # split path (vision_heads=2, d_in=2048)
     (1, 2, 2, 30, 30, 256, False, True),
+    # long K/V streams: 12-wave split-KV form with deferred rescale + combine (nkv % 64 != 0 -> 16x16 kernel), and the
+    # 32x32x16 kernel k_attn32 (dh = 64, nkv % 64 == 0, no bias / mask): 6 waves exact, 4 waves with ragged queries, GQA
+    (1, 2, 2, 100, 5000, 64, False, False),
+    (1, 2, 2, 576, 8192, 64, False, False),
+    (2, 2, 1, 120, 4096, 64, False, False),
+    (1, 1, 1, 192, 16384, 64, False, False),
 ]
 
 
@@ -198,6 +204,37 @@ def test_attention(B, H, Hkv, nq, nkv, dh, use_bias, causal, split):
     err = (got - ref).abs().max().item()
     # plain mode: P and the output are rounded to bf16 (2^-9); split mode: ~1e-5
     assert err < (2e-2 if not split else 2e-4), err
+
+
+@pytest.mark.parametrize("nq,nkv,gain", [(192, 8192, 1.0), (100, 5000, 1.0), (192, 8192, 12.0), (120, 4096, 12.0)])
+def test_attention_rescale_events(nq, nkv, gain):
+    """Scores whose running maximum keeps growing along the key axis (keys sorted by a ramp): every few tiles exceed the
+    deferred-rescale threshold, so the rare rescale path of both long-stream kernels runs many times; and one query whose
+    scores are hugely negative except for a late key (reference moved from a tiny to a large maximum)."""
+    o = ops()
+    B, H, dh = 1, 2, 64
+    q = bf_round(torch.from_numpy(synth.randn((B, nq, H, dh), 61))).to(DEV)
+    k = torch.from_numpy(synth.randn((B, nkv, H, dh), 62))
+    ramp = torch.linspace(0.0, 3.0, nkv).view(1, nkv, 1, 1)
+    # logits std grows ~15x along the stream; gain 12 pushes late logits > 2^100 above the first tile's maximum in the log2
+    # domain, which overflows k_attn32's fixed-reference fast stream and must trigger its classic (rescaling) re-run
+    k = bf_round(k * (0.2 + ramp) * gain).to(DEV)
+    v = bf_round(torch.from_numpy(synth.randn((B, nkv, H, dh), 63))).to(DEV)
+    qb, kb, vb = (o.cast(t.reshape(-1, H * dh), False) for t in (q, k, v))
+    out = o.attention(qb, kb, vb, batch=B, n_heads=H, n_kv_heads=H, nq=nq, nkv=nkv, dh=dh,
+                      q_strides=(nq * H * dh, H * dh, dh), k_strides=(nkv * H * dh, H * dh, dh),
+                      v_strides=(nkv * H * dh, H * dh, dh), scale=1.0 / math.sqrt(dh))
+    got = o.to_f32(out).double().cpu().view(B, nq, H, dh)
+    # the plain-bf16 kernels pre-multiply Q by scale*log2(e) and re-round it to bf16; at these logit magnitudes (hundreds) that
+    # rounding moves the weights visibly, so the reference applies the same operand rounding and works in the exp2 domain
+    c = torch.tensor(1.0 / math.sqrt(dh), dtype=torch.float32) * torch.tensor(1.4426950408889634, dtype=torch.float32)
+    qs = bf_round(q.cpu() * c)
+    qd, kd, vd = (t.double().cpu().transpose(1, 2) for t in (qs, k, v))
+    lg = qd @ kd.transpose(-1, -2)
+    wgt = torch.exp2(lg - lg.max(-1, keepdim=True).values)
+    ref = ((wgt / wgt.sum(-1, keepdim=True)) @ vd).transpose(1, 2)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 3e-2
 
 
 def test_dwconv3x3_gelu():
