@@ -1004,7 +1004,7 @@ __global__ void __launch_bounds__(256, (NT16 <= 48 ? 2 : 1)) k_gemm_ln(GemmLnArg
 //   * a wave handles the same 16 table rows for up to SB scenes at once: the positional table (805 MB fp32 at
 //     512 x 512 x 768) is read from HBM exactly once per step, into registers, whatever the caches do.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int LNR_WAVES = 12;      // 3 waves per SIMD: ~150 VGPRs (af 32 + table 16 + packed outputs 32 + fragments) without spilling
+constexpr int LNR_WAVES = 8;       // 2 waves per SIMD: ~220 VGPRs (af 32 + two table chunks 32 + packed outputs 32 + fragments); 12 waves spilled (0.93 vs 0.72 ms)
 template <int NG, int SB>
 __global__ void __launch_bounds__(LNR_WAVES * 64) k_gemm_ln_rows(GemmLnArgs g, int n_ptiles, int scenes, int64_t rows_per_scene) {
     constexpr int N = NG * 64;
@@ -1092,15 +1092,23 @@ __global__ void __launch_bounds__(LNR_WAVES * 64) k_gemm_ln_rows(GemmLnArgs g, i
                 rstd[sc] = 1.0f / sqrtf(rstd[sc] * inv_n + g.eps);
             }
             // ---- pass 3: output, one 64-column group at a time; the table chunk is loaded once for all SB scenes ----
+            // the table chunk of group G+1 is requested while group G is computed (every chunk is an HBM miss)
+            f32x4 pen[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pen[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float *ps = g.post ? g.post + (p % g.post_rows) * N + cofs : nullptr;
+            if (ps) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pen[t] = *reinterpret_cast<const f32x4 *>(ps + 4 * t);
+            }
 #pragma unroll 1
             for (int G = 0; G < NG; ++G) {
                 f32x4 pe[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) pe[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (g.post) {
-                    const float *ps = g.post + (p % g.post_rows) * N + 64 * G + cofs;
+                for (int t = 0; t < 4; ++t) pe[t] = pen[t];
+                if (ps && G + 1 < NG) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) pe[t] = *reinterpret_cast<const f32x4 *>(ps + 4 * t);
+                    for (int t = 0; t < 4; ++t) pen[t] = *reinterpret_cast<const f32x4 *>(ps + 64 * (G + 1) + 4 * t);
                 }
                 uint32_t out[SB][8];
 #pragma unroll
