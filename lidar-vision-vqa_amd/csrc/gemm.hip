@@ -404,7 +404,12 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_bf16(GemmArgs g) {
 //   read frags(tile it, k-half 1) | 32 MFMA (k-half 0) | vmcnt(4) lgkmcnt(0), barrier -> the slots of tile it are
 //   free and tile it+1 has landed | DMA W(it+2), A(it+3) | read frags(tile it+1, k-half 0) | 32 MFMA (k-half 1)
 // ---------------------------------------------------------------------------------------------------------
-template <int GELU>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// NT = streaming (non-temporal) C stores: the 256x256 projections write 128 KiB of C per workgroup, 4 MiB per round of an
+// XCD's 32 CUs -- exactly its L2 -- and evict the A panels / W tiles the other workgroups are about to re-read
+template <int GELU, bool NT = false>
 __device__ __forceinline__ void store_chunk8(const GemmArgs &g, int64_t z, int64_t row, int col, float (&v)[8]) {
     if (g.bias) {
         const float4 b0 = *reinterpret_cast<const float4 *>(g.bias + col), b1 = *reinterpret_cast<const float4 *>(g.bias + col + 4);
@@ -427,18 +432,25 @@ __device__ __forceinline__ void store_chunk8(const GemmArgs &g, int64_t z, int64
         v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
     }
     if (g.c32) {
-        *reinterpret_cast<float4 *>(g.c32 + o) = *reinterpret_cast<float4 *>(v);
-        *reinterpret_cast<float4 *>(g.c32 + o + 4) = *reinterpret_cast<float4 *>(v + 4);
+        if (NT) {
+            __builtin_nontemporal_store(f32x4v{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4v *>(g.c32 + o));
+            __builtin_nontemporal_store(f32x4v{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4v *>(g.c32 + o + 4));
+        } else {
+            *reinterpret_cast<float4 *>(g.c32 + o) = *reinterpret_cast<float4 *>(v);
+            *reinterpret_cast<float4 *>(g.c32 + o + 4) = *reinterpret_cast<float4 *>(v + 4);
+        }
     }
     if (g.c16) {
         const uint4 hb = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-        *reinterpret_cast<uint4 *>(g.c16 + o) = hb;
+        if (NT) __builtin_nontemporal_store(u32x4{hb.x, hb.y, hb.z, hb.w}, reinterpret_cast<u32x4 *>(g.c16 + o));
+        else    *reinterpret_cast<uint4 *>(g.c16 + o) = hb;
         if (g.c16lo) {
             const uint4 lb = make_uint4(pack_bf16(v[0] - __uint_as_float(hb.x << 16), v[1] - __uint_as_float(hb.x & 0xffff0000u)),
                                         pack_bf16(v[2] - __uint_as_float(hb.y << 16), v[3] - __uint_as_float(hb.y & 0xffff0000u)),
                                         pack_bf16(v[4] - __uint_as_float(hb.z << 16), v[5] - __uint_as_float(hb.z & 0xffff0000u)),
                                         pack_bf16(v[6] - __uint_as_float(hb.w << 16), v[7] - __uint_as_float(hb.w & 0xffff0000u)));
-            *reinterpret_cast<uint4 *>(g.c16lo + o) = lb;
+            if (NT) __builtin_nontemporal_store(u32x4{lb.x, lb.y, lb.z, lb.w}, reinterpret_cast<u32x4 *>(g.c16lo + o));
+            else    *reinterpret_cast<uint4 *>(g.c16lo + o) = lb;
         }
     }
 }
@@ -603,7 +615,7 @@ __global__ void __launch_bounds__(512) k_gemm_256(GemmArgs g) {
             float v[8];
             *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8);
             *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8 + 4);
-            store_chunk8<GELU>(g, z, m0 + wm * 128 + ii * 16 + rr, n0 + wn * WC + c8 * 8, v);
+            store_chunk8<GELU, true>(g, z, m0 + wm * 128 + ii * 16 + rr, n0 + wn * WC + c8 * 8, v);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
