@@ -513,7 +513,12 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     constexpr float THR = 6.0f;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
-    const int grp = blockIdx.x / a.nqt, qtile = blockIdx.x - grp * a.nqt;
+    // Workgroup order: hardware deals block ids round-robin over the 8 XCDs, and each XCD has its own L2.  The nqt workgroups
+    // that stream the SAME K/V range (same batch, head, split; different query tiles) get block ids 8 apart, i.e. the same XCD
+    // back to back, so the range leaves HBM once and the repeats are L2 hits (in plain id order the three copies went to three XCDs).
+    const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+    const int qtile = pos % a.nqt, grp = (pos / a.nqt) * 8 + xcd;
+    if (grp >= a.B * a.H * a.nsplit) return;                    // padding of the group count to a multiple of 8 (whole workgroup)
     const int sp = grp % a.nsplit, h = (grp / a.nsplit) % a.H, b = grp / (a.nsplit * a.H);
     const int hk = h / (a.H / a.Hkv);
     const int q0 = qtile * (NW * 32) + wid * 32;
@@ -990,7 +995,8 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
         }
         if (pl.k32) {
             const size_t lds = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16;  // three K+V slots + the redo flag
-            const int64_t nwg = (int64_t)a.B * a.H * a.nsplit * a.nqt;
+            const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
+            const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;       // groups padded to the 8 XCDs (see the kernel's id mapping)
             if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
             if (pl.k32 == 6) hipLaunchKernelGGL(k_attn32<6>, dim3((unsigned)nwg), dim3(384), lds, st, a);
             else             hipLaunchKernelGGL(k_attn32<4>, dim3((unsigned)nwg), dim3(256), lds, st, a);
