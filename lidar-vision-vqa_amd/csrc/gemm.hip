@@ -455,6 +455,10 @@ __device__ __forceinline__ void store_chunk8(const GemmArgs &g, int64_t z, int64
     }
 }
 
+// Measured dead end: a persistent form of this kernel (one workgroup per CU walking tiles, the next tile's three A tiles
+// requested before the current epilogue, its W tiles after it, epilogue slab in the W ring) needs ~8 more VGPRs than the 256
+// available with 128 accumulators + two fragment sets: the spills sit in the prologue / tail code and their reloads wait on
+// vmcnt, i.e. on the very requests that were meant to fly under the epilogue -- 2.99 vs 2.50 ms on the K|V projection.
 template <int GELU>
 __global__ void __launch_bounds__(512) k_gemm_256(GemmArgs g) {
     constexpr int BM = 256, BN = 256, BK = 64, NW = 8;
