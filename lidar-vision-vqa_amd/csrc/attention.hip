@@ -758,6 +758,10 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
         }
 }
 
+// Measured dead end: a short-K/V companion of k_attn32 (all of K/V of one head staged once in LDS, every wave walking its own
+// 32-query tiles with no barrier -- the shape of the cross-attention onto 196 image patches) was correct but slower than the
+// 4-wave 16x16 form on the headline shape (65 vs 58 us): with ~2.5 waves per SIMD in a single dispatch round the time is one
+// wave's serial latency (~4000 cycles per 32x64 tile step), not issue throughput; the 16-query form has 4x more, shorter waves.
 // merge the KV splits: out = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s
 __global__ void __launch_bounds__(256) k_attn_combine(AttnArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;

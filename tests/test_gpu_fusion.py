@@ -172,6 +172,11 @@ ATT_CASES = [
     (1, 2, 2, 576, 8192, 64, False, False),
     (2, 2, 1, 120, 4096, 64, False, False),
     (1, 1, 1, 192, 16384, 64, False, False),
+    # short K/V with many queries (the patch cross-attention shapes): ragged key tile, ragged queries, GQA
+    (1, 12, 12, 1000, 196, 64, False, False),
+    (2, 4, 2, 577, 64, 64, False, False),
+    (1, 2, 2, 2048, 256, 64, False, False),
+    (3, 2, 2, 200, 130, 64, False, False),
 ]
 
 
