@@ -758,6 +758,9 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
         }
 }
 
+// Measured dead end: a bf16x3 form of k_attn32 (hi + lo operands, three MFMAs per product, two 32-KiB LDS slots) is correct
+// but needs 246 VGPRs (two sets of Q fragments, hi/lo P and V fragments): two waves per SIMD, i.e. one 6-wave workgroup per
+// CU, and 8.4 ms against 6.6 ms for the 12-wave 16x16 bf16x3 kernel; capped at 168 VGPRs it spills 224 bytes.
 // Measured dead end: a short-K/V companion of k_attn32 (all of K/V of one head staged once in LDS, every wave walking its own
 // 32-query tiles with no barrier -- the shape of the cross-attention onto 196 image patches) was correct but slower than the
 // 4-wave 16x16 form on the headline shape (65 vs 58 us): with ~2.5 waves per SIMD in a single dispatch round the time is one
