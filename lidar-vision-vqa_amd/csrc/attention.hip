@@ -91,8 +91,19 @@ __global__ void __launch_bounds__(NW * 64) k_attn(AttnArgs a) {
     // ds_read_b64_tr_b16); two stages
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = lane >> 4, l15 = lane & 15;
-    // 1-D grid, query tile fastest: the nqt workgroups that stream the same K/V range are adjacent in dispatch order
-    const int grp = blockIdx.x / a.nqt, qtile = blockIdx.x - grp * a.nqt;
+    // 1-D grid.  The nqt workgroups that stream the same K/V range (same batch, head, split) should share an L2: hardware deals
+    // block ids round-robin over the 8 XCDs, so the long-stream forms (NW >= 8) give them ids 8 apart (same XCD, back to back;
+    // the group count is padded to a multiple of 8 by the launcher).  Short forms keep plain order (query tile fastest).
+    int grp, qtile;
+    if (NW >= 8) {
+        const int xcd = blockIdx.x & 7, pos = blockIdx.x >> 3;
+        qtile = pos % a.nqt;
+        grp = (pos / a.nqt) * 8 + xcd;
+        if (grp >= a.B * a.H * a.nsplit) return;                // padding workgroup (whole workgroup leaves)
+    } else {
+        grp = blockIdx.x / a.nqt;
+        qtile = blockIdx.x - grp * a.nqt;
+    }
     const int sp = grp % a.nsplit, h = (grp / a.nsplit) % a.H, b = grp / (a.nsplit * a.H);
     const int hk = h / (a.H / a.Hkv);
     const int q0 = qtile * (NW * QW) + wid * QW;
@@ -874,7 +885,8 @@ template <int DHP, int NSPLIT, int QT, int NW> int launch_attn_qt(AttnArgs &a, h
     const size_t lds = (size_t)(2 * 2 * NS * KVB * ((DHP == 64 && NW >= 8) ? DHP : DHP + 8)) * sizeof(uint16_t);   // two K+V stages
     if (lds > 64 * 1024)
         hipFuncSetAttribute((const void *)k_attn<DHP, NSPLIT, QT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int64_t nwg = (int64_t)a.B * a.H * a.nsplit * a.nqt;
+    const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
+    const int64_t nwg = (NW >= 8 ? (ngrp + 7) / 8 * 8 : ngrp) * a.nqt;      // NW >= 8: XCD-aware id mapping in the kernel
     if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
     dim3 grid((unsigned)nwg);
     hipLaunchKernelGGL((k_attn<DHP, NSPLIT, QT, NW>), grid, dim3(NW * 64), lds, st, a);
