@@ -862,11 +862,6 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, 
         const int f = atoi(ev);
         if ((f == 4 || f == 8 || f == 12) && p.qt == 1 && dhp <= 64) p.nw = f;
     }
-    if (const char *ev = getenv("LVQ_ATTN_WIDE")) {    // experiment: 12 waves x (2|3) query tiles per wave
-        const int f = atoi(ev);
-        if (f == 2 && dhp == 64 && !split) { p.qt = 2; p.nw = 12; }
-        if (f == 9 && dhp == 64 && !split) { p.qt = 2; p.nw = 9; }
-    }
     p.nqt = (nq + 16 * p.nw * p.qt - 1) / (16 * p.nw * p.qt);
     const int64_t base = (int64_t)p.nqt * n_heads * batch;
     const int n_tiles = (nkv + KVB - 1) / KVB;
@@ -902,8 +897,6 @@ template <int DHP, int NSPLIT> int launch_attn(AttnArgs &a, const AttnPlan &pl, 
         if (pl.nw == 12) return launch_attn_qt<DHP, NSPLIT, 1, (DHP <= 64) ? 12 : 4>(a, st);
         if (pl.nw == 8) return launch_attn_qt<DHP, NSPLIT, 1, (DHP <= 64) ? 8 : 4>(a, st);
     }
-    if (DHP == 64 && NSPLIT == 1 && pl.nw == 9 && pl.qt == 2) return launch_attn_qt<DHP, NSPLIT, (DHP == 64 && NSPLIT == 1) ? 2 : 1, (DHP == 64 && NSPLIT == 1) ? 9 : 4>(a, st);
-    if (DHP == 64 && NSPLIT == 1 && pl.nw == 12 && pl.qt == 2) return launch_attn_qt<DHP, NSPLIT, (DHP == 64 && NSPLIT == 1) ? 2 : 1, (DHP == 64 && NSPLIT == 1) ? 12 : 4>(a, st);
     if (!(DHP > 64 && NSPLIT == 3) && pl.qt >= 2) return launch_attn_qt<DHP, NSPLIT, (DHP > 64 && NSPLIT == 3) ? 1 : 2, 4>(a, st);
     return launch_attn_qt<DHP, NSPLIT, 1, 4>(a, st);
 }
