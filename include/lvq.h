@@ -212,6 +212,16 @@ int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *
 int lvq_dwconv3x3_gelu(const float *bev, const float *w9, const float *bias, int batch, int ch, int h, int w,
                        lvq_bf16 *tokens_hi, lvq_bf16 *tokens_lo, lvq_stream_t stream);
 
+/* Sparse BEV bridge = PointPillarScatter.forward (pointpillar_scatter.py:14-37) followed by VATLiDAR.refine
+ * (vat_lidar.py:212-221: depthwise 3x3 conv, padding 1, + GELU) and the flatten to tokens [batch*ny*nx, ch], WITHOUT
+ * materialising the dense [batch, ch, ny, nx] canvas: only an int32 index map (pillar row or -1) is scattered into `ws`.
+ * Bit-identical to lvq_pillar_scatter + lvq_dwconv3x3_gelu.  feat [m_cap, ch] fp32, coords (b, z, y, x) with nz == 1,
+ * rows >= *n_voxels_dev skipped (NULL = all m_cap rows).  tokens_lo may be NULL (plain bf16). */
+size_t lvq_pillar_dwconv_workspace_bytes(int batch, int ny, int nx);
+int lvq_pillar_dwconv3x3_gelu(const float *feat, const int32_t *coords_bzyx, int64_t m_cap, const int32_t *n_voxels_dev,
+                              int ch, int batch, int ny, int nx, const float *w9, const float *bias, lvq_bf16 *tokens_hi,
+                              lvq_bf16 *tokens_lo, void *ws, size_t ws_bytes, lvq_stream_t stream);
+
 /* out[r, :] = x[r, :] * alpha + add[(r % add_rows), :]  (query = query + view_embed chunk,
  * vat_lidar.py:259-270; prefix * prefix_scale, trainer.py:581,594) -- fp32 elementwise; add may be NULL. */
 int lvq_scale_add_rows(const float *x, const float *add, int64_t add_rows, float alpha, int64_t rows, int d,

@@ -190,6 +190,109 @@ __global__ void __launch_bounds__(256) k_dwconv3x3_gelu(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sparse BEV bridge: PointPillarScatter + depthwise 3x3 + GELU -> tokens WITHOUT the dense canvas.
+// The pillar canvas is ~93 % zeros at nuScenes densities, and the dense route writes it (268 MB memset + scatter for 4 scenes),
+// reads it back and only then produces the 134 MB of tokens.  Here a dense int32 INDEX map (pillar row or -1; 4 MB) is the
+// only thing scattered; the conv kernel keeps each lane's 3 x 6 neighbourhood indices in registers for all 64 channels and
+// gathers the few live taps from the [M, C] pillar features (L2-resident).  Tap order and fmaf chain are those of
+// k_dwconv3x3_gelu and a zero tap leaves the accumulator unchanged exactly, so the tokens are bit-identical to the dense route.
+// Blocks whose whole 6 x 66 neighbourhood is empty write the per-channel constant GELU(bias).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_pillar_index(const int32_t *__restrict__ coords, int64_t m_cap, const int32_t *__restrict__ n_live,
+                                                      int batch, int ny, int nx, int32_t *__restrict__ idx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t m = n_live ? (int64_t)*n_live : m_cap;
+    if (m > m_cap) m = m_cap;
+    if (i >= m) return;
+    const int4 c = reinterpret_cast<const int4 *>(coords)[i];      // (b, z, y, x), nz == 1
+    if (c.x < 0 || c.x >= batch || c.z < 0 || c.z >= ny || c.w < 0 || c.w >= nx) return;
+    idx[((int64_t)c.x * ny + c.z) * nx + c.w] = (int32_t)i;
+}
+
+template <bool LO>
+__global__ void __launch_bounds__(256) k_pillar_dwconv_gelu(const float *__restrict__ feat, const int32_t *__restrict__ idx,
+                                                            const float *__restrict__ w9, const float *__restrict__ bias,
+                                                            int C, int H, int W, uint16_t *__restrict__ thi, uint16_t *__restrict__ tlo) {
+    __shared__ __attribute__((aligned(16))) uint16_t oh[DW_RY][DW_PX][DW_C + 8];
+    __shared__ __attribute__((aligned(16))) uint16_t ol[LO ? DW_RY : 1][LO ? DW_PX : 1][DW_C + 8];
+    __shared__ int any_live;
+    const int x0 = blockIdx.x * DW_PX, y0 = blockIdx.y * DW_RY;
+    const int cblocks = (C + DW_C - 1) / DW_C;
+    const int b = blockIdx.z / cblocks, c0 = (blockIdx.z % cblocks) * DW_C;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int gx = x0 + lane;
+    if (tid == 0) any_live = 0;
+    __syncthreads();
+    // this lane's neighbourhood: rows y0-1 .. y0+RY, columns gx-1, gx, gx+1 (-1 outside the image / empty)
+    int nb[DW_RY + 2][3];
+    bool mine = false;
+#pragma unroll
+    for (int r = 0; r < DW_RY + 2; ++r) {
+        const int gy = y0 + r - 1;
+        const bool rin = gy >= 0 && gy < H;
+        const int32_t *rowp = idx + ((int64_t)b * H + (rin ? gy : 0)) * W;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int xx = gx + k - 1;
+            nb[r][k] = (rin && xx >= 0 && xx < W) ? rowp[xx] : -1;
+            mine = mine || nb[r][k] >= 0;
+        }
+    }
+    if (wid == 0 && __any(mine)) any_live = 1;                  // every wave loads the same neighbourhood
+    __syncthreads();
+    if (!any_live) {
+        // constant rows: GELU(bias[c]) for every pixel of the block
+        for (int e = tid; e < DW_RY * DW_PX * DW_C; e += 256) {
+            const int c = e % DW_C, px = (e / DW_C) % DW_PX, ry = e / (DW_C * DW_PX), gc = c0 + c;
+            const float v = gc < C ? gelu_erf(bias ? bias[gc] : 0.f) : 0.f;
+            const uint16_t h = f32_to_bf16(v);
+            oh[ry][px][c] = h;
+            if (LO) ol[ry][px][c] = f32_to_bf16(v - bf16_to_f32(h));
+        }
+    } else {
+#pragma unroll 1
+        for (int ci = 0; ci < DW_C / 4; ++ci) {
+            const int c = wid * (DW_C / 4) + ci, gc = c0 + c;
+            if (gc >= C) break;                                 // wave-uniform
+            float wk[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) wk[k] = w9[gc * 9 + k];
+            const float bs = bias ? bias[gc] : 0.f;
+            float win[3][3];
+#pragma unroll
+            for (int r = 0; r < DW_RY + 2; ++r) {
+                float *wr = win[r % 3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) wr[k] = nb[r][k] >= 0 ? feat[(int64_t)nb[r][k] * C + gc] : 0.f;
+                if (r >= 2) {
+                    const int ry = r - 2;
+                    float acc = bs;
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) acc = fmaf(win[(ry + rr) % 3][k], wk[rr * 3 + k], acc);
+                    acc = gelu_erf(acc);
+                    const uint16_t h = f32_to_bf16(acc);
+                    oh[ry][lane][c] = h;
+                    if (LO) ol[ry][lane][c] = f32_to_bf16(acc - bf16_to_f32(h));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nc = (C - c0) < DW_C ? (C - c0) : DW_C;
+    for (int e = tid; e < DW_RY * DW_PX * (DW_C / 8); e += 256) {
+        const int ch = e & 7, px = (e >> 3) & (DW_PX - 1), ry = e / (8 * DW_PX);
+        const int ox = x0 + px, gy = y0 + ry;
+        if (ox < W && gy < H && ch * 8 < nc) {
+            const int64_t o = ((int64_t)b * H * W + (int64_t)gy * W + ox) * C + c0 + ch * 8;
+            *reinterpret_cast<uint4 *>(thi + o) = *reinterpret_cast<const uint4 *>(&oh[ry][px][ch * 8]);
+            if (LO) *reinterpret_cast<uint4 *>(tlo + o) = *reinterpret_cast<const uint4 *>(&ol[ry][px][ch * 8]);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_scale_add_rows(const float *__restrict__ x, const float *__restrict__ add,
                                                         int64_t add_rows, float alpha, int64_t rows, int d,
                                                         float *__restrict__ out) {
@@ -299,6 +402,32 @@ extern "C" int lvq_dwconv3x3_gelu(const float *bev, const float *w9, const float
     dim3 grid((unsigned)lvq_cdiv(w, DW_PX), (unsigned)lvq_cdiv(h, DW_RY), (unsigned)(batch * cblocks));
     if (tokens_lo) hipLaunchKernelGGL(k_dwconv3x3_gelu<true>, grid, dim3(256), 0, lvq_s(stream), bev, w9, bias, ch, h, w, tokens_hi, tokens_lo);
     else           hipLaunchKernelGGL(k_dwconv3x3_gelu<false>, grid, dim3(256), 0, lvq_s(stream), bev, w9, bias, ch, h, w, tokens_hi, tokens_lo);
+    return lvq_launch_status();
+}
+
+extern "C" size_t lvq_pillar_dwconv_workspace_bytes(int batch, int ny, int nx) {
+    return lvq_align((size_t)batch * ny * nx * sizeof(int32_t)) + 256;
+}
+
+extern "C" int lvq_pillar_dwconv3x3_gelu(const float *feat, const int32_t *coords_bzyx, int64_t m_cap, const int32_t *n_voxels_dev,
+                                         int ch, int batch, int ny, int nx, const float *w9, const float *bias, lvq_bf16 *tokens_hi,
+                                         lvq_bf16 *tokens_lo, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+    if (batch <= 0 || ch <= 0 || ny <= 0 || nx <= 0 || m_cap < 0 || !w9 || !tokens_hi) return LVQ_EINVAL;
+    if (m_cap > 0 && (!feat || !coords_bzyx)) return LVQ_EINVAL;
+    if (ch % 8) return LVQ_EUNSUPPORTED;
+    if ((((uintptr_t)tokens_hi | (uintptr_t)tokens_lo | (uintptr_t)coords_bzyx) & 15) || m_cap > 0x7fffffff) return LVQ_EUNSUPPORTED;
+    LvqArena arena(ws, ws_bytes);
+    int32_t *idx = arena.take<int32_t>((size_t)batch * ny * nx);
+    if (!arena.ok) return LVQ_EWORKSPACE;
+    const int cblocks = (ch + DW_C - 1) / DW_C;
+    if ((int64_t)batch * cblocks > 65535 || lvq_cdiv(ny, DW_RY) > 65535) return LVQ_EUNSUPPORTED;
+    hipStream_t st = lvq_s(stream);
+    hipMemsetAsync(idx, 0xFF, (size_t)batch * ny * nx * sizeof(int32_t), st);           // -1 = empty cell
+    if (m_cap > 0)
+        hipLaunchKernelGGL(k_pillar_index, dim3((unsigned)lvq_cdiv(m_cap, 256)), dim3(256), 0, st, coords_bzyx, m_cap, n_voxels_dev, batch, ny, nx, idx);
+    dim3 grid((unsigned)lvq_cdiv(nx, DW_PX), (unsigned)lvq_cdiv(ny, DW_RY), (unsigned)(batch * cblocks));
+    if (tokens_lo) hipLaunchKernelGGL(k_pillar_dwconv_gelu<true>, grid, dim3(256), 0, st, feat, idx, w9, bias, ch, ny, nx, tokens_hi, tokens_lo);
+    else           hipLaunchKernelGGL(k_pillar_dwconv_gelu<false>, grid, dim3(256), 0, st, feat, idx, w9, bias, ch, ny, nx, tokens_hi, tokens_lo);
     return lvq_launch_status();
 }
 

@@ -250,10 +250,34 @@ class VATLiDAR(_HipModule):
         _, x = ops.layernorm(x32, self.norm_tokens.weight, self.norm_tokens.bias, self.norm_tokens.eps, split, post=pe)
         return x
 
+    def _tokens_to_model(self, t: BF, H: int, W: int, dev) -> BF:
+        pe = self._pe_table(H, W, dev)
+        C = t[0].shape[1]
+        if ops.linear_ln_supported(self.d_model, C):
+            return ops.linear_ln(t, self._w(self.proj.weight), self.proj.bias, self.norm_tokens.weight, self.norm_tokens.bias,
+                                 self.norm_tokens.eps, post=pe, tag="bev_proj_ln")
+        x32, _ = ops.linear(t, self._w(self.proj.weight), self.proj.bias, out_f32=True)
+        _, x = ops.layernorm(x32, self.norm_tokens.weight, self.norm_tokens.bias, self.norm_tokens.eps, self._split(), post=pe)
+        return x
+
+    def forward_pillars(self, pillar_features: torch.Tensor, coords_bzyx: torch.Tensor, n_live: Optional[torch.Tensor],
+                        batch: int, H: int, W: int) -> torch.Tensor:
+        """Same result as forward(PointPillarScatter(pillars)) without the dense BEV canvas: the scatter and the refine conv
+        (vat_lidar.py:212-221) run as one sparse gather (ops.pillar_dwconv3x3_gelu, bit-identical tokens)."""
+        self._guard(pillar_features)
+        C = pillar_features.shape[1]
+        t = ops.pillar_dwconv3x3_gelu(_f32(pillar_features), coords_bzyx, n_live, batch, H, W,
+                                      self.refine[0].weight.detach().reshape(C, 9).contiguous(), self.refine[0].bias, self._split())
+        x = self._tokens_to_model(t, H, W, pillar_features.device)
+        return self._decode(x, batch, H, W)
+
     def forward(self, bev: torch.Tensor) -> torch.Tensor:
         self._guard(bev)
         B, C, H, W = bev.shape
         x = self.bev_tokens(bev)
+        return self._decode(x, B, H, W)
+
+    def _decode(self, x: BF, B: int, H: int, W: int) -> torch.Tensor:
         # queries + per-view embedding (vat_lidar.py:259-270), broadcast over the batch
         ve = self.view_embed.detach().float().repeat_interleave(self.nq_per_view, dim=0).contiguous()
         q0 = ops.scale_add_rows(self.query.detach().float().contiguous(), ve)

@@ -178,6 +178,30 @@ def dwconv3x3_gelu(bev: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]
     return hi, lo
 
 
+_PD_WS = {}
+
+
+def pillar_dwconv3x3_gelu(feat: torch.Tensor, coords: torch.Tensor, n_live: Optional[torch.Tensor], batch: int, ny: int, nx: int,
+                          w: torch.Tensor, b: Optional[torch.Tensor], split: bool) -> BF:
+    """Sparse BEV bridge: PointPillarScatter + depthwise 3x3 + GELU -> tokens BF [batch*ny*nx, C] without the dense canvas
+    (bit-identical to pillar_scatter + dwconv3x3_gelu).  feat [M, C] fp32, coords [M, 4] int32 (b, z, y, x), rows >= n_live[0] skipped."""
+    F.require_cuda(feat, coords, w, b, n_live)
+    m, C = feat.shape
+    hi, lo = _bf_empty((batch * ny * nx, C), feat.device, split)
+    L = F.lib()
+    nbytes = int(L.lvq_pillar_dwconv_workspace_bytes(F.cint(batch), F.cint(ny), F.cint(nx)))
+    key = feat.device.index if feat.device.index is not None else torch.cuda.current_device()
+    ws = _PD_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=feat.device)
+        _PD_WS[key] = ws
+    import ctypes
+    rc = L.lvq_pillar_dwconv3x3_gelu(F.ptr(feat), F.ptr(coords), F.i64(m), F.ptr(n_live), F.cint(C), F.cint(batch), F.cint(ny), F.cint(nx),
+                                     F.ptr(w), F.ptr(b), F.ptr(hi), F.ptr(lo), F.ptr(ws), ctypes.c_size_t(ws.numel()), F.stream_ptr(feat.device))
+    F.check(rc, "lvq_pillar_dwconv3x3_gelu")
+    return hi, lo
+
+
 def scale_add_rows(x: torch.Tensor, add: Optional[torch.Tensor], alpha: float = 1.0) -> torch.Tensor:
     F.require_cuda(x, add)
     rows, d = x.shape

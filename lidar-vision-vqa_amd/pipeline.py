@@ -64,9 +64,10 @@ class Cfg(dict):
 
 
 class FusionPipeline(torch.nn.Module):
-    def __init__(self, cfg: PipelineConfig, device, precision: Optional[str] = None):
+    def __init__(self, cfg: PipelineConfig, device, precision: Optional[str] = None, dense_bev: bool = False):
         super().__init__()
         self.cfg = cfg
+        self.dense_bev = dense_bev          # True: materialise the BEV canvas as the reference does (returned as out["bev"])
         rng = list(cfg.pc_range)
         self.gen3d = lidar.VoxelGeneratorWrapper(cfg.voxel_3d, rng, 4, cfg.t_3d, cfg.max_voxels_3d)
         self.genp = lidar.VoxelGeneratorWrapper(cfg.voxel_pillar, rng, 4, cfg.t_pillar, cfg.max_pillars)
@@ -96,8 +97,16 @@ class FusionPipeline(torch.nn.Module):
         # pillar branch -> BEV
         voxp, cop, nump, svop = self.genp.generate_batch_device(points, scene_off, S)
         pf = self.pillar_vfe.forward_device(voxp, nump, cop, svop[S:])
-        bev = self.scatter.forward_device(pf, cop, S, svop[S:])
-        lidar_tokens = self.vat_lidar(bev)                                  # [S, nq, d]
+        if self.dense_bev:
+            # reference dataflow: PointPillarScatter materialises the [S, C, H, W] canvas, VATLiDAR consumes it
+            bev = self.scatter.forward_device(pf, cop, S, svop[S:])
+            lidar_tokens = self.vat_lidar(bev)                              # [S, nq, d]
+        else:
+            # sparse BEV bridge (default): scatter + VATLiDAR's refine conv as one gather over an index map -- same tokens bit
+            # for bit (tests/test_gpu_pipeline.py), no 268 MB canvas write + read per 4 scenes
+            bev = None
+            h, w = self.cfg.bev_hw
+            lidar_tokens = self.vat_lidar.forward_pillars(pf, cop, svop[S:], S, h, w)
         fused = self.fuse(lidar_tokens, patches)                            # [S, nq, d]
         return dict(fused=fused, lidar_tokens=lidar_tokens, voxel_features=feat3, voxel_coords=co3, voxel_num_points=num3,
                     scene_voxel_off=svo3, pillar_features=pf, pillar_coords=cop, scene_pillar_off=svop, bev=bev)

@@ -55,3 +55,39 @@ def test_pipeline_no_host_sync_and_determinism():
     c = pipe(pts, off2, patches)
     assert bool(torch.isfinite(c["fused"]).all())
     assert torch.equal(c["fused"][0], a[0])                                       # scene 0 unaffected by its neighbours
+
+
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+def test_sparse_bev_bridge_is_bit_identical(prec):
+    """Default pipeline (scatter + refine conv as one sparse gather, no dense canvas) vs the reference dataflow
+    (PointPillarScatter canvas -> VATLiDAR): identical tokens, bit for bit; plus the op against scatter + dwconv directly,
+    with pillars on the image border, a ragged grid and a channel count that is not a multiple of 64."""
+    from lidar_vision_vqa_amd import lidar, ops, synth
+    cfg = small_cfg(dist="C")
+    sparse = P.FusionPipeline(cfg, DEV, precision=prec)
+    dense = P.FusionPipeline(cfg, DEV, precision=prec, dense_bev=True)
+    dense.load_state_dict(sparse.state_dict())
+    pts, off, patches, _, _ = P.synthetic_batch(cfg, 2, 1001, DEV)
+    a, b = sparse(pts, off, patches), dense(pts, off, patches)
+    assert a["bev"] is None and b["bev"] is not None
+    assert torch.equal(a["lidar_tokens"], b["lidar_tokens"])
+    assert torch.equal(a["fused"], b["fused"])
+    # op level
+    B, C, H, W, M = 3, 40, 37, 70, 500
+    g = torch.Generator().manual_seed(5)
+    cells = torch.randperm(B * H * W, generator=g)[:M]
+    cells[:4] = torch.tensor([0, W - 1, (H - 1) * W, B * H * W - 1])           # image corners
+    coords = torch.stack((cells // (H * W), torch.zeros_like(cells), (cells // W) % H, cells % W), 1).to(torch.int32).to(DEV)
+    feat = torch.from_numpy(synth.randn((M + 7, C), 71)).to(DEV)                # 7 rows past n_live must be ignored
+    coords = torch.cat((coords, coords[:7]), 0).contiguous()
+    n_live = torch.tensor([M], dtype=torch.int32, device=DEV)
+    w9 = torch.from_numpy(synth.randn((C, 9), 72, 0.3)).to(DEV)
+    bias = torch.from_numpy(synth.randn((C,), 73)).to(DEV)
+    sc = lidar.PointPillarScatter(type("Cfg", (), {"NUM_BEV_FEATURES": C})(), np.array([W, H, 1]))
+    canvas = sc.forward_device(feat, coords, B, n_live)
+    for split in (False, True):
+        ref = ops.dwconv3x3_gelu(canvas, w9, bias, split)
+        got = ops.pillar_dwconv3x3_gelu(feat, coords, n_live, B, H, W, w9, bias, split)
+        assert torch.equal(ref[0], got[0])
+        if split:
+            assert torch.equal(ref[1], got[1])
