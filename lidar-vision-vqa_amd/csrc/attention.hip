@@ -815,10 +815,12 @@ __global__ void __launch_bounds__(256) k_attn_combine(AttnArgs a) {
 
 // launch geometry shared by lvq_attention_workspace_bytes and lvq_attention_bf16
 struct AttnPlan { int qt, nw, nqt, nsplit, k32; };
-// k_attn32 geometry (0 = not applicable): 32 queries per wave, 6 or 4 waves, at most 1/8 of the query slots padding
+// k_attn32 geometry (0 = not applicable): 32 queries per wave, 4 or 6 waves, at most 1/8 of the query slots padding
 int plan_k32_waves(int nq, int nkv, int dh, bool split) {
     if (split || dh != 64 || nkv < 4096 || (nkv % KVB) != 0 || getenv("LVQ_ATTN_NO32") != nullptr) return 0;
-    for (int nw : {6, 4}) {
+    const int force = getenv("LVQ_ATTN32_NW") ? atoi(getenv("LVQ_ATTN32_NW")) : 0;
+    for (int nw : {4, 6}) {       // measured on 576 x 262144: 4 waves 2.29 ms, 6 waves 2.63, 3 waves 2.71 (three workgroups per CU at 4)
+        if (force && nw != force) continue;
         const int64_t tile = 32 * nw, padded = (nq + tile - 1) / tile * tile;
         if ((padded - nq) * 8 <= nq) return nw;
     }
@@ -1010,8 +1012,8 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
             const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
             const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;       // groups padded to the 8 XCDs (see the kernel's id mapping)
             if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
-            if (pl.k32 == 6) hipLaunchKernelGGL(k_attn32<6>, dim3((unsigned)nwg), dim3(384), lds, st, a);
-            else             hipLaunchKernelGGL(k_attn32<4>, dim3((unsigned)nwg), dim3(256), lds, st, a);
+            if (pl.k32 == 6)      hipLaunchKernelGGL(k_attn32<6>, dim3((unsigned)nwg), dim3(384), lds, st, a);
+            else                  hipLaunchKernelGGL(k_attn32<4>, dim3((unsigned)nwg), dim3(256), lds, st, a);
             if (a.nsplit > 1) {
                 const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
                 hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
