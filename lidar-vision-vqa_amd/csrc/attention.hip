@@ -907,6 +907,10 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, 
         if (ns > n_tiles / 8) ns = n_tiles / 8;
         if (ns < 1) ns = 1;
         if (ns > 64) ns = 64;
+        if (const char *ev = getenv("LVQ_ATTN_NSPLIT")) {       // test hook: force the KV split count (1 = direct output path)
+            const int f = atoi(ev);
+            if (f >= 1 && f <= 64 && f <= n_tiles) ns = f;
+        }
         p.nsplit = ns;
         return p;
     }

@@ -211,6 +211,14 @@ def test_attention(B, H, Hkv, nq, nkv, dh, use_bias, causal, split):
     assert err < (2e-2 if not split else 2e-4), err
 
 
+def test_attention_long_stream_unsplit(monkeypatch):
+    """k_attn32's direct-output path (one KV split: taken in production when batch x heads x query tiles >= 4096)."""
+    monkeypatch.setenv("LVQ_ATTN_NSPLIT", "1")
+    test_attention(2, 2, 1, 120, 4096, 64, False, False, False)
+    monkeypatch.setenv("LVQ_ATTN_NSPLIT", "3")
+    test_attention(1, 2, 2, 576, 8192, 64, False, False, False)
+
+
 @pytest.mark.parametrize("nq,nkv,gain", [(192, 8192, 1.0), (100, 5000, 1.0), (192, 8192, 12.0), (120, 4096, 12.0)])
 def test_attention_rescale_events(nq, nkv, gain):
     """Scores whose running maximum keeps growing along the key axis (keys sorted by a ramp): every few tiles exceed the
