@@ -249,3 +249,26 @@ def test_full_size_properties_cfg3():
     assert int(torch.minimum(dv["unq_cnt"][:m], torch.tensor(10, device=DEV)).sum()) == int(num.sum())
     k = dv["unq_key"][:m].long()
     assert bool((k[1:] > k[:-1]).all())                                 # sortedness
+
+
+@pytest.mark.parametrize("with_distance,abs_xyz,filters,T", [(False, True, [64], 20), (True, True, [64], 20), (False, False, [32], 12),
+                                                             (True, False, [64], 32), (True, True, [48], 7)])
+def test_pillar_vfe_fast_kernel_flag_combinations(with_distance, abs_xyz, filters, T, monkeypatch):
+    """The single-layer fast kernel (k_pillar_vfe1) against the CPU restatement and against the generic kernel for every
+    feature layout (WITH_DISTANCE / USE_ABSLOTE_XYZ), odd T and channel counts below 64."""
+    lid = L()
+    scenes = [torch.from_numpy(masked("C", 3000, 700 + s)).to(DEV) for s in range(2)]
+    gen = lid.VoxelGeneratorWrapper(synth.VOXEL_PILLAR, RNG, 4, T, 30000)
+    bd = lid.voxelize_batch(gen, scenes)
+    cfg = Cfg(USE_NORM=True, WITH_DISTANCE=with_distance, USE_ABSLOTE_XYZ=abs_xyz, NUM_FILTERS=filters)
+    m = lid.__all__["PillarVFE"](model_cfg=cfg, num_point_features=4, voxel_size=list(synth.VOXEL_PILLAR),
+                                 point_cloud_range=RNG, grid_size=[512, 512, 1]).to(DEV).eval()
+    synth.load_seeded(m, 91)
+    fast = m(dict(bd))["pillar_features"].cpu()
+    monkeypatch.setenv("LVQ_PILLAR_VFE_GENERIC", "1")
+    generic = m(dict(bd))["pillar_features"].cpu()
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = LO.pillar_vfe(bd["voxels"].cpu().numpy(), bd["voxel_num_points"].cpu().numpy(), bd["voxel_coords"].cpu().numpy(), sd,
+                        list(synth.VOXEL_PILLAR), RNG, filters, True, with_distance, abs_xyz)
+    assert (fast - ref).abs().max().item() < 2e-5
+    assert (fast - generic).abs().max().item() < 2e-5
