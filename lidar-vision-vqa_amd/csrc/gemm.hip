@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_bf16(GemmArgs g) {
     constexpr int BK = 64;
     constexpr int WROWS = NW / 2;                  // wave grid WROWS x 2
     constexpr int NT = NW * 64;
-    constexpr int NSTAGE = NW == 8 ? 3 : 2;
+    constexpr int NSTAGE = (NW == 8 || (GLDS && BM == 64)) ? 3 : 2;    // 64x64 tiles serve the small latency-bound GEMMs: deeper ring
     constexpr int TM = BM / (WROWS * 16), TN = BN / 32;      // MFMA tiles per wave
     constexpr int LA = BM * 8 / NT, LB = BN * 8 / NT;        // 16-byte chunks per thread per stage
     constexpr int STAGE = (BM + BN) * 128;
@@ -1315,7 +1315,7 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
     if (tiles > 0x7fffffff) return LVQ_EUNSUPPORTED;
     g.ntx = (int)lvq_cdiv(n, bm);
     dim3 grid((unsigned)tiles, 1, (unsigned)batch);
-    const size_t lds = (size_t)2 * (bm + bm) * 128;
+    const size_t lds = (size_t)((bm == 64 && dma) ? 3 : 2) * (bm + bm) * 128;
 #define LVQ_LAUNCH(BM_, DMA_, GE_) hipLaunchKernelGGL((k_gemm_bf16<BM_, BM_, DMA_, GE_, 4>), grid, dim3(256), lds, st, g)
     if (bm == 128) {
         if (dma) { if (ge) LVQ_LAUNCH(128, 1, 1); else LVQ_LAUNCH(128, 1, 0); }
