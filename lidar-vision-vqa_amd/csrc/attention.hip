@@ -684,8 +684,10 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
             bf16x4 a00, a01, a10, a11, b00, b01, b10, b11;
             if (kb == 0) {
                 a00 = lds_tr_read_o<0>(e0);        a01 = lds_tr_read_o<1024>(o0);  a10 = lds_tr_read_o<0>(e1);        a11 = lds_tr_read_o<1024>(o1);
+                b00 = lds_tr_read_o<2048>(e0);     b01 = lds_tr_read_o<3072>(o0);  b10 = lds_tr_read_o<2048>(e1);     b11 = lds_tr_read_o<3072>(o1);
             } else {
                 a00 = lds_tr_read_o<4096>(e0);     a01 = lds_tr_read_o<5120>(o0);  a10 = lds_tr_read_o<4096>(e1);     a11 = lds_tr_read_o<5120>(o1);
+                b00 = lds_tr_read_o<6144>(e0);     b01 = lds_tr_read_o<7168>(o0);  b10 = lds_tr_read_o<6144>(e1);     b11 = lds_tr_read_o<7168>(o1);
             }
             uint32_t pk[8];
             float ls = 0.f;
@@ -698,14 +700,9 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
             lsum += ls;
             uint4 u0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), u1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             const bf16x8 pf0 = *reinterpret_cast<bf16x8 *>(&u0), pf1 = *reinterpret_cast<bf16x8 *>(&u1);
-            lds_tr_wait(a00, a01, a10, a11);
+            lds_tr_wait4(a00, a01, a10, a11);
             o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(a00, a01, 0, 1, 2, 3, 4, 5, 6, 7), pf0, o[0], 0, 0, 0);
             o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(a10, a11, 0, 1, 2, 3, 4, 5, 6, 7), pf0, o[1], 0, 0, 0);
-            if (kb == 0) {
-                b00 = lds_tr_read_o<2048>(e0);     b01 = lds_tr_read_o<3072>(o0);  b10 = lds_tr_read_o<2048>(e1);     b11 = lds_tr_read_o<3072>(o1);
-            } else {
-                b00 = lds_tr_read_o<6144>(e0);     b01 = lds_tr_read_o<7168>(o0);  b10 = lds_tr_read_o<6144>(e1);     b11 = lds_tr_read_o<7168>(o1);
-            }
             lds_tr_wait(b00, b01, b10, b11);
             o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(b00, b01, 0, 1, 2, 3, 4, 5, 6, 7), pf1, o[0], 0, 0, 0);
             o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(b10, b11, 0, 1, 2, 3, 4, 5, 6, 7), pf1, o[1], 0, 0, 0);
