@@ -576,14 +576,24 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     const uint16_t *vbase = a.v + (int64_t)wave_b * a.v_bs + (int64_t)wave_hk * a.v_hs;
     const int r8 = lane >> 3, pch = lane & 7;
     constexpr int NPC = (16 + NW - 1) / NW;                    // DMA pieces per wave per tile (K pieces 0..7, V pieces 8..15)
+    // per piece: a loop-invariant 32-bit lane offset; the tile base is a scalar 64-bit add (a per-tile 64-bit multiply per
+    // lane and piece was ~60 vector issues per tile on a loop that is issue-bound)
+    uint32_t doff[NPC];
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+        const int pc = wid + NW * j, isv = (pc >> 3) & 1, piece = pc & 7, row = piece * 8 + r8;
+        const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+        doff[j] = (uint32_t)(row * (isv ? a.ldv : a.ldk) + ((pch ^ f) << 3));
+    }
+    const int64_t kstep = (int64_t)KVB * a.ldk, vstep = (int64_t)KVB * a.ldv;
     auto dma = [&](int t, int slot) __attribute__((always_inline)) {
+        const uint16_t *kt = kbase + t * kstep, *vt = vbase + t * vstep;       // wave-uniform
 #pragma unroll
         for (int j = 0; j < NPC; ++j) {
             const int pc = wid + NW * j;                       // wave-uniform
             if (pc < 16) {
-                const int isv = pc >> 3, piece = pc & 7, row = piece * 8 + r8;
-                const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
-                const uint16_t *src = (isv ? vbase + ((int64_t)t * KVB + row) * a.ldv : kbase + ((int64_t)t * KVB + row) * a.ldk) + ((pch ^ f) << 3);
+                const int isv = pc >> 3, piece = pc & 7;
+                const uint16_t *src = (isv ? vt : kt) + doff[j];
                 uint16_t *dst = smem + slot * TILE_E + isv * (KVB * KROW) + piece * 512;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
