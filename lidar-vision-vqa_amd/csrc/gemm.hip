@@ -410,8 +410,11 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // NT = streaming (non-temporal) C stores: the 256x256 projections write 128 KiB of C per workgroup, 4 MiB per round of an
 // XCD's 32 CUs -- exactly its L2 -- and evict the A panels / W tiles the other workgroups are about to re-read
 template <int GELU, bool NT = false>
-__device__ __forceinline__ void store_chunk8(const GemmArgs &g, int64_t z, int64_t row, int col, float (&v)[8]) {
-    if (g.bias) {
+__device__ __forceinline__ void store_chunk8(const GemmArgs &g, int64_t z, int64_t row, int col, float (&v)[8], const float *bias_regs = nullptr) {
+    if (bias_regs) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bias_regs[e];
+    } else if (g.bias) {
         const float4 b0 = *reinterpret_cast<const float4 *>(g.bias + col), b1 = *reinterpret_cast<const float4 *>(g.bias + col + 4);
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
     }
@@ -459,13 +462,16 @@ __device__ __forceinline__ void store_chunk8(const GemmArgs &g, int64_t z, int64
 // requested before the current epilogue, its W tiles after it, epilogue slab in the W ring) needs ~8 more VGPRs than the 256
 // available with 128 accumulators + two fragment sets: the spills sit in the prologue / tail code and their reloads wait on
 // vmcnt, i.e. on the very requests that were meant to fly under the epilogue -- 2.99 vs 2.50 ms on the K|V projection.
-template <int GELU>
+template <int GELU, int ANT>
 __global__ void __launch_bounds__(512) k_gemm_256(GemmArgs g) {
     constexpr int BM = 256, BN = 256, BK = 64, NW = 8;
     constexpr int TM = 8, TN = 4;                   // 16x16 MFMA tiles per wave: 128 rows x 64 columns
     constexpr int ASLOT = BM * 128, WSLOT = BN * 128;          // 32 KiB each
     constexpr int WBASE = 3 * ASLOT;                // A ring: 3 slots at 0; W ring: 2 slots behind it (160 KiB in all)
     constexpr int NA = BM / (8 * NW), NWL = BN / (8 * NW);     // global_load_lds per wave per A / W tile (4, 4)
+    // ANT: the A stream is loaded non-temporal (evict-first) so that it does not displace W in the 4 MiB L2 -- right when few
+    // N-tiles share an A panel (K|V projection, 6 tiles: 969 -> 1021 TFLOP/s), wrong when many do (8192^3, 32 tiles: 1290 -> 1100)
+    constexpr int A_CPOL = ANT ? 2 : 0;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3;
@@ -505,7 +511,7 @@ __global__ void __launch_bounds__(512) k_gemm_256(GemmArgs g) {
     };
     auto a_piece = [&](const uint16_t *A, int slot, int i) __attribute__((always_inline)) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A + i * a_step),
-                                         (__attribute__((address_space(3))) void *)(smem + slot * ASLOT + wid * 1024 + i * (NW * 1024)), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(smem + slot * ASLOT + wid * 1024 + i * (NW * 1024)), 16, 0, A_CPOL);
     };
     auto w_piece = [&](const uint16_t *W, int slot, int i) __attribute__((always_inline)) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(W + i * w_step),
@@ -596,6 +602,14 @@ __global__ void __launch_bounds__(512) k_gemm_256(GemmArgs g) {
     if (n_it >= 3) k_tile(true, false, true);
     if (n_it >= 2) k_tile(false, false, false);
     read_frags(as, ws, 1, a1, b1);
+    // a lane stores the same 8-column chunk (lane % 8) in every pass of the epilogue: its bias values are fetched once per tile,
+    // and requested here so that the load flies under the last 64 MFMAs (at the top of the epilogue it cost ~1 us per tile)
+    float bv[8];
+    {
+        const int colb = n0 + wn * 64 + (lane % 8) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = g.bias ? g.bias[colb + e] : 0.f;
+    }
     mma(a0, b0);
     mma(a1, b1);
     __builtin_amdgcn_s_barrier();                              // the epilogue reuses the A ring as its transpose slab
@@ -619,7 +633,7 @@ __global__ void __launch_bounds__(512) k_gemm_256(GemmArgs g) {
             float v[8];
             *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8);
             *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8 + 4);
-            store_chunk8<GELU, true>(g, z, m0 + wm * 128 + ii * 16 + rr, n0 + wn * WC + c8 * 8, v);
+            store_chunk8<GELU, true>(g, z, m0 + wm * 128 + ii * 16 + rr, n0 + wn * WC + c8 * 8, v, bv);
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1150,8 +1164,10 @@ __global__ void __launch_bounds__(LNR_WAVES * 64) k_gemm_ln_rows(GemmLnArgs g, i
                 for (int sc = 0; sc < SB; ++sc)
                     if (s0 + sc < scenes && rows[sc] < g.M) {
                         uint16_t *dst = g.y16 + rows[sc] * N + 64 * G + cofs;
-                        *reinterpret_cast<uint4 *>(dst) = make_uint4(out[sc][0], out[sc][1], out[sc][2], out[sc][3]);
-                        *reinterpret_cast<uint4 *>(dst + 8) = make_uint4(out[sc][4], out[sc][5], out[sc][6], out[sc][7]);
+                        // streaming stores: the tokens are consumed by the next kernel from HBM anyway (6.4 GB per 16 scenes), and
+                        // dirty lines left in L2 / Infinity Cache were costing that kernel ~4 % while they drained
+                        __builtin_nontemporal_store(u32x4{out[sc][0], out[sc][1], out[sc][2], out[sc][3]}, reinterpret_cast<u32x4 *>(dst));
+                        __builtin_nontemporal_store(u32x4{out[sc][4], out[sc][5], out[sc][6], out[sc][7]}, reinterpret_cast<u32x4 *>(dst + 8));
                     }
             }
         }
@@ -1262,14 +1278,17 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
         (m / 256) * (n / 256) <= 0x7fffffff && ok256 != 0 && getenv("LVQ_GEMM_NO256X256") == nullptr && getenv("LVQ_GEMM_NO256") == nullptr) {
         const size_t lds = (size_t)5 * 256 * 128;              // A ring 3 x 32 KiB + W ring 2 x 32 KiB
         if (ok256 < 0)
-            ok256 = hipFuncSetAttribute((const void *)k_gemm_256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                    hipFuncSetAttribute((const void *)k_gemm_256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+            ok256 = hipFuncSetAttribute((const void *)k_gemm_256<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                    hipFuncSetAttribute((const void *)k_gemm_256<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                    hipFuncSetAttribute((const void *)k_gemm_256<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                    hipFuncSetAttribute((const void *)k_gemm_256<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
         if (ok256) {
             g.ntx = (int)(n / 256);
             g.ntiles = (m / 256) * (n / 256);
             dim3 grid((unsigned)g.ntiles, 1, (unsigned)batch);
-            if (ge) hipLaunchKernelGGL(k_gemm_256<1>, grid, dim3(512), lds, st, g);
-            else    hipLaunchKernelGGL(k_gemm_256<0>, grid, dim3(512), lds, st, g);
+            const bool ant = g.ntx <= 8;
+            if (ge) { if (ant) hipLaunchKernelGGL((k_gemm_256<1, 1>), grid, dim3(512), lds, st, g); else hipLaunchKernelGGL((k_gemm_256<1, 0>), grid, dim3(512), lds, st, g); }
+            else    { if (ant) hipLaunchKernelGGL((k_gemm_256<0, 1>), grid, dim3(512), lds, st, g); else hipLaunchKernelGGL((k_gemm_256<0, 0>), grid, dim3(512), lds, st, g); }
             return lvq_launch_status();
         }
         (void)hipGetLastError();
