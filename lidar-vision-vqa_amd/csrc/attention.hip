@@ -914,6 +914,19 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, 
         if (ns > n_tiles / 8) ns = n_tiles / 8;
         if (ns < 1) ns = 1;
         if (ns > 64) ns = 64;
+        {
+            // dispatch-round quantisation: 3 (4-wave) or 2 (6-wave) workgroups fit per CU; among the split counts near the
+            // target pick the one whose last round is fullest (576 queries, 4 scenes: 18 splits = 5.6 rounds, 16 = 5.0)
+            const int64_t slots = (int64_t)256 * (p.k32 == 4 ? 3 : 2);
+            double best = 1e30;
+            int best_ns = ns;
+            for (int c = ns > 4 ? ns - 4 : 1; c <= ns + 1 && c <= 64 && c <= (n_tiles / 8 > 0 ? n_tiles / 8 : 1); ++c) {
+                const int64_t wgs = base * c;
+                const double waste = (double)((wgs + slots - 1) / slots * slots) / (double)wgs;
+                if (wgs >= 3 * slots && waste < best - 1e-9) { best = waste; best_ns = c; }
+            }
+            ns = best_ns;
+        }
         if (const char *ev = getenv("LVQ_ATTN_NSPLIT")) {       // test hook: force the KV split count (1 = direct output path)
             const int f = atoi(ev);
             if (f >= 1 && f <= 64 && f <= n_tiles) ns = f;
