@@ -88,7 +88,7 @@ class VoxelGeneratorWrapper:
         svo = torch.empty((n_scenes + 1,), dtype=torch.int32, device=dev)
         L = F.lib()
         nbytes = L.lvq_voxelize_hard_workspace_bytes(F.i64(n), F.cint(n_scenes))
-        ws = workspace(nbytes, dev)
+        ws = workspace(nbytes, dev, getattr(self, "ws_tag", "vox"))      # generators that run on different streams need their own
         rc = L.lvq_voxelize_hard(F.ptr(points), F.ptr(scene_off), F.i64(n), F.cint(n_scenes), F.cint(c),
                                  F.f32x(self.range), F.f32x(self.vsize), F.i32x(self.grid.tolist()),
                                  F.cint(self.t), F.cint(self.max_voxels), F.cint(int(self.break_on_cap)),

@@ -18,6 +18,7 @@ masks first like the reference does).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -68,8 +69,10 @@ class FusionPipeline(torch.nn.Module):
         super().__init__()
         self.cfg = cfg
         self.dense_bev = dense_bev          # True: materialise the BEV canvas as the reference does (returned as out["bev"])
+        self._side = None                   # side stream of the 3-D voxel branch (created on first use)
         rng = list(cfg.pc_range)
         self.gen3d = lidar.VoxelGeneratorWrapper(cfg.voxel_3d, rng, 4, cfg.t_3d, cfg.max_voxels_3d)
+        self.gen3d.ws_tag = "vox3"           # runs on the side stream, concurrently with the pillar voxeliser
         self.genp = lidar.VoxelGeneratorWrapper(cfg.voxel_pillar, rng, 4, cfg.t_pillar, cfg.max_pillars)
         gp = lidar.grid_size_from(rng, cfg.voxel_pillar)
         self.mean_vfe = lidar.MeanVFE(Cfg(), 4)
@@ -91,9 +94,17 @@ class FusionPipeline(torch.nn.Module):
     def forward(self, points: torch.Tensor, scene_off: torch.Tensor, patches: torch.Tensor) -> Dict[str, torch.Tensor]:
         """points [sum N, 4] fp32, scene_off [S+1] int32, patches [S, P, d] fp32 -- all device resident."""
         S = patches.shape[0]
-        # 3-D branch: "32k-point cloud voxelised to a 0.1 m grid" + per-voxel mean
-        vox3, co3, num3, svo3 = self.gen3d.generate_batch_device(points, scene_off, S)
-        feat3 = self.mean_vfe.forward_device(vox3, num3, svo3[S:])
+        # 3-D branch: "32k-point cloud voxelised to a 0.1 m grid" + per-voxel mean.  It shares nothing but the input points with the
+        # pillar branch and consists of ~10 launch-latency-bound kernels, so it runs on a side stream under the pillar / fusion
+        # kernels and is joined before returning (its own workspace: tag "vox3").
+        main = torch.cuda.current_stream(points.device)
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=points.device)
+        side = main if os.environ.get("LVQ_NO_SIDE_STREAM") else self._side
+        side.wait_stream(main) if side is not main else None
+        with torch.cuda.stream(side):
+            vox3, co3, num3, svo3 = self.gen3d.generate_batch_device(points, scene_off, S)
+            feat3 = self.mean_vfe.forward_device(vox3, num3, svo3[S:])
         # pillar branch -> BEV
         voxp, cop, nump, svop = self.genp.generate_batch_device(points, scene_off, S)
         pf = self.pillar_vfe.forward_device(voxp, nump, cop, svop[S:])
@@ -108,6 +119,10 @@ class FusionPipeline(torch.nn.Module):
             h, w = self.cfg.bev_hw
             lidar_tokens = self.vat_lidar.forward_pillars(pf, cop, svop[S:], S, h, w)
         fused = self.fuse(lidar_tokens, patches)                            # [S, nq, d]
+        if side is not main:
+            main.wait_stream(side)
+        for t_ in (vox3, co3, num3, svo3, feat3):
+            t_.record_stream(main)
         return dict(fused=fused, lidar_tokens=lidar_tokens, voxel_features=feat3, voxel_coords=co3, voxel_num_points=num3,
                     scene_voxel_off=svo3, pillar_features=pf, pillar_coords=cop, scene_pillar_off=svop, bev=bev)
 
