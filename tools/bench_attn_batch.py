@@ -1,3 +1,4 @@
+"""k_attn32 at 4 and 16 scenes per launch (LVQ_ATTN_NSPLIT sweeps)."""
 import os, sys, math
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch

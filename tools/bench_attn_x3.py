@@ -1,3 +1,4 @@
+"""bf16x3 long-stream attention (4, 12, 576, 262144, 64) timed for LVQ_ATTN_NW sweeps."""
 import os, sys, math
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""K|V-projection GEMM (16 scenes) timed in different contexts: with / without bias, right after a 6.4 GB fill (dirty lines in
+L2 / Infinity Cache, as after the token kernel), after torch.cuda.empty_cache() (fresh pages).  Used for same-box A/B runs."""
 import os, sys, math
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
