@@ -37,6 +37,13 @@ int lvq_binned_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t
                              int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes,
                              hipStream_t st);
 
+// hash-balanced slabs + input-order placement (voxel_hashed.hip): the default hard path
+size_t lvq_hashed_hard_workspace_bytes(int64_t n, int n_scenes);
+int lvq_hashed_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n, int n_scenes, int c, const float *range_host,
+                             const float *vsize_host, const int32_t *grid_host, int max_pts, int max_voxels, float *voxels,
+                             int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes,
+                             hipStream_t st);
+
 namespace {
 
 struct Geom {
@@ -560,8 +567,11 @@ extern "C" size_t lvq_voxelize_hard_workspace_bytes(int64_t n_points, int n_scen
     SizerAdapter a;
     HardWs w;
     hard_layout(a, w, n_points, n_scenes);
-    const size_t binned = lvq_binned_hard_workspace_bytes(n_points, n_scenes);
-    return a.s.total() > binned ? a.s.total() : binned;
+    size_t need = a.s.total();
+    const size_t binned = lvq_binned_hard_workspace_bytes(n_points, n_scenes), hashed = lvq_hashed_hard_workspace_bytes(n_points, n_scenes);
+    if (binned > need) need = binned;
+    if (hashed > need) need = hashed;
+    return need;
 }
 
 extern "C" int lvq_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n_points, int n_scenes, int c,
@@ -582,7 +592,14 @@ extern "C" int lvq_voxelize_hard(const float *pts, const int32_t *scene_off, int
     }
     int64_t need = n_points < (int64_t)n_scenes * max_voxels ? n_points : (int64_t)n_scenes * max_voxels;
     if (voxel_capacity < need || !pts || !voxels || !coords_bzyx || !num_pts) return LVQ_EINVAL;
-    if (!break_on_cap && getenv("LVQ_VOXEL_LEGACY") == nullptr) {   // slab-binned path; the hash kernels below are the fallback
+    // default: hash-balanced slabs (voxel_hashed.hip); shapes it does not take go to the slab-binned path, then to the
+    // global-hash kernels below.  LVQ_VOXEL_BINNED / LVQ_VOXEL_LEGACY force the older paths (tests, A/B timing).
+    if (!break_on_cap && getenv("LVQ_VOXEL_LEGACY") == nullptr && getenv("LVQ_VOXEL_BINNED") == nullptr) {
+        const int rc = lvq_hashed_voxelize_hard(pts, scene_off, n_points, n_scenes, c, range_host, vsize_host, grid_host, max_pts,
+                                                max_voxels, voxels, coords_bzyx, num_pts, scene_voxel_off, ws, ws_bytes, st);
+        if (rc != LVQ_EUNSUPPORTED) return rc;
+    }
+    if (!break_on_cap && getenv("LVQ_VOXEL_LEGACY") == nullptr) {
         const int rc = lvq_binned_voxelize_hard(pts, scene_off, n_points, n_scenes, c, range_host, vsize_host, grid_host, max_pts,
                                                 max_voxels, voxels, coords_bzyx, num_pts, scene_voxel_off, ws, ws_bytes, st);
         if (rc != LVQ_EUNSUPPORTED) return rc;

@@ -1,0 +1,534 @@
+// csrc/voxel_hashed.hip -- hard voxeliser, third design: hash-balanced slabs + input-order placement (gfx950).
+//
+// Reference semantics (data_processor.py:16-61,133-180 -> spconv Point2VoxelCPU3d): voxel id = first
+// appearance in input order, first T points of a cell in input order, `continue` cap.  Order-independent formulation:
+//   voxel id(cell)  = rank of the cell's FIRST point among all first points   (prefix popcount over 1 flag per point)
+//   slot(point)     = number of points of the same cell with a smaller index
+//
+// The slab-binned version (voxel_binned.hip, 11 stream operations, 128 us for 8 x 65 536 points) lost its time in
+//   (1) ~2500 key-contiguous slabs -> one global atomic per (block, slab) pair in the histogram and in the scatter
+//       (260 k memory-side atomics each), plus hot slabs around the sensor origin that need a second, dense kernel;
+//   (2) placement in slab order: 16-byte stores scattered over first-appearance ranks + a 13-step binary search;
+//   (3) launches: three memsets and three single-workgroup scans.
+// This file keeps the idea (sort points into LDS-sized groups that hold whole cells, rank inside LDS) and changes:
+//   * slab = top bits of a BIJECTIVE 32-bit mix of the key: every cell still lands in exactly one slab, but slabs are
+//     statistically balanced (no hot slabs), a power-of-two count of ~1000-point slabs is enough (4x fewer global
+//     atomics), and ONE slab kernel serves every slab: an LDS open-addressing table (CAS insert, per-cell intrusive
+//     list, atomicMin first index, count) -> O(points) LDS work instead of the O(n_s^2) compare loop.
+//   * the slab scan is folded into the scatter kernel (every block rescans the <= 8192-entry histogram in LDS);
+//     flags -> words keeps only block-local prefixes (k_words); the scan over the per-block totals, the first-rank at
+//     the scene starts and the capped scene offsets are recomputed in the prologue of every placement block
+//     (a few hundred L2-resident values) -- no single-workgroup scan kernels are left.
+//   * placement runs in INPUT order: consecutive first points own consecutive output rows (that is what first-appearance
+//     order means), so a wave stages its first points in LDS and streams rows*T*16 contiguous bytes with full 1 KB
+//     wave stores (zero padding included); only non-first points (multi-point cells) issue scattered 16-byte stores.
+//     coords / num_points leave as dense stores, cell coordinates are recomputed from the point (no key decode).
+//   5 kernels + 1 memset.  Unsupported shapes (C != 4, T > 127, key space >= 2^31, n > 8 M, > 1024 scenes, `break` cap) -> LVQ_EUNSUPPORTED
+//   and the caller falls back to voxel_binned.hip / the hash kernels in voxel.hip.
+#include "common.h"
+
+namespace vh {
+
+struct Geom {
+    float lo[3];
+    float vs[3];
+    int grid[3];
+};
+
+constexpr int MAX_SLABS = 8192;
+constexpr int BIN_NT = 1024;          // threads of the histogram / scatter blocks
+constexpr int BIN_PPT = 4;            // points per thread
+constexpr int SLAB_NT = 512;          // threads of a slab workgroup
+constexpr int SLAB_CAP = 2048;        // points of a slab ranked in LDS (larger slabs: same code on global arrays)
+constexpr int SLAB_TS = 2 * SLAB_CAP; // table slots in LDS
+
+struct Ws {
+    int32_t *ghist, *cursor;          // [MAX_SLABS+1] each, contiguous (one memset)
+    int32_t *gstart;                  // [MAX_SLABS+2]
+    int32_t *sidx;                    // [n] original index, grouped by slab
+    uint32_t *smix;                   // [n] mixed key (equal mix <=> equal cell)
+    uint8_t *fb;                      // [n+64] by ORIGINAL index: min(count, T) for the first point of a cell, else 0
+    int2 *rec;                        // [n]    by ORIGINAL index, non-first points: (first index of the cell, slot)
+    uint64_t *fmask;                  // [nwords+1] first-point flags, 64 points per word
+    int32_t *wloc;                    // [nwords+2] exclusive popcount prefix of a word inside its 4096-point block
+    int32_t *btot;                    // [MAX_KB+2] first points per 4096-point block
+    int32_t *g_bucket;                // [n]      oversize slabs: global stand-ins for the LDS arrays
+    uint32_t *g_key;                  // [2n+64]
+    int32_t *g_cnt, *g_first, *g_start;
+};
+
+template <typename A> void layout(A &a, Ws &w, int64_t n, int n_scenes) {
+    const int64_t nwords = (n + 63) / 64;
+    w.ghist = a.template take<int32_t>(2 * (MAX_SLABS + 64));
+    w.cursor = w.ghist ? w.ghist + MAX_SLABS + 64 : nullptr;
+    w.gstart = a.template take<int32_t>(MAX_SLABS + 2);
+    w.sidx = a.template take<int32_t>(n + 1);
+    w.smix = a.template take<uint32_t>(n + 1);
+    w.fb = a.template take<uint8_t>(n + 64);
+    w.rec = a.template take<int2>(n + 1);
+    w.fmask = a.template take<uint64_t>(nwords + 1);
+    w.wloc = a.template take<int32_t>(nwords + 2);
+    w.btot = a.template take<int32_t>(4096);
+    w.g_bucket = a.template take<int32_t>(n + 1);
+    w.g_key = a.template take<uint32_t>(2 * n + 64);
+    w.g_cnt = a.template take<int32_t>(2 * n + 64);
+    w.g_first = a.template take<int32_t>(2 * n + 64);
+    w.g_start = a.template take<int32_t>(2 * n + 64);
+}
+
+struct SizerAdapter {
+    LvqSizer s;
+    template <typename T> T *take(size_t n) { s.template take<T>(n); return nullptr; }
+};
+
+__device__ __forceinline__ int find_scene(const int32_t *off, int n_scenes, int i) {
+    int lo = 0, hi = n_scenes;
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// cell coordinates (cx, cy, cz) of a point: floor((p - lo) / vs) in IEEE fp32, in-range test as the reference does it
+__device__ __forceinline__ bool cell_of(float x, float y, float z, const Geom &g, int cc[3]) {
+    const float p[3] = {x, y, z};
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float d = p[j] - g.lo[j];
+        const float q = d / g.vs[j];
+        const float f = floorf(q);
+        const bool in = (f >= 0.0f) && (f < (float)g.grid[j]);
+        ok = ok && in;
+        cc[j] = in ? (int)f : -1;
+    }
+    return ok;
+}
+
+// bijective 32-bit mix (odd multiplies and xor-shifts); mix(0) == 0, and keys enter as key + 1, so a mixed key is never 0
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+// mixed key of point i, 0 for a point outside the grid
+__device__ __forceinline__ uint32_t mixed_key(const float4 p, int scene, const Geom &g) {
+    int cc[3];
+    if (!cell_of(p.x, p.y, p.z, g, cc)) return 0u;
+    const uint32_t key = (uint32_t)(((scene * g.grid[0] + cc[0]) * g.grid[1] + cc[1]) * g.grid[2] + cc[2]);   // < 2^31 (host check)
+    return mix32(key + 1u);
+}
+
+__device__ __forceinline__ int block_excl_scan(int v, int *wave_tot, int nwaves, int &total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    int wbase = 0, tot = 0;
+    for (int w = 0; w < nwaves; ++w) {
+        const int t = wave_tot[w];
+        if (w < wid) wbase += t;
+        tot += t;
+    }
+    __syncthreads();
+    total = tot;
+    return wbase + incl - v;
+}
+
+// ---- K1: per-slab histogram in LDS; points outside the grid get their flag byte cleared here ----
+__global__ void __launch_bounds__(BIN_NT) k_hist(const float4 *__restrict__ pts, int n, Geom g, int n_scenes, int shift, int nslabs,
+                                                 const int32_t *__restrict__ scene_off, Ws w) {
+    extern __shared__ int32_t lh[];
+    for (int b = threadIdx.x; b < nslabs; b += BIN_NT) lh[b] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * (BIN_NT * BIN_PPT);
+#pragma unroll
+    for (int u = 0; u < BIN_PPT; ++u) {
+        const int i = base + u * BIN_NT + threadIdx.x;
+        if (i < n) {
+            const uint32_t m = mixed_key(pts[i], find_scene(scene_off, n_scenes, i), g);
+            if (m) atomicAdd(&lh[shift >= 32 ? 0 : (int)(m >> shift)], 1);
+            else w.fb[i] = 0;
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nslabs; b += BIN_NT)
+        if (lh[b]) atomicAdd(&w.ghist[b], lh[b]);
+}
+
+// ---- K2: scatter (original index, mixed key) grouped by slab; the slab scan is redone per block in LDS ----
+__global__ void __launch_bounds__(BIN_NT) k_scatter(const float4 *__restrict__ pts, int n, Geom g, int n_scenes, int shift, int nslabs,
+                                                    const int32_t *__restrict__ scene_off, Ws w) {
+    extern __shared__ int32_t lds[];
+    __shared__ int wave_tot[BIN_NT / 64];
+    int32_t *lh = lds, *lb = lds + nslabs;
+    // exclusive scan of the global histogram: thread t owns `per` consecutive slabs
+    const int per = (nslabs + BIN_NT - 1) / BIN_NT;
+    int c = 0;
+    for (int j = 0; j < per; ++j) {
+        const int b = threadIdx.x * per + j;
+        if (b < nslabs) c += w.ghist[b];
+    }
+    int tot;
+    int ex = block_excl_scan(c, wave_tot, BIN_NT / 64, tot);
+    for (int j = 0; j < per; ++j) {
+        const int b = threadIdx.x * per + j;
+        if (b < nslabs) {
+            lb[b] = ex;
+            lh[b] = 0;
+            if (blockIdx.x == 0) w.gstart[b] = ex;
+            ex += w.ghist[b];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.gstart[nslabs] = tot;
+    __syncthreads();
+    const int base = blockIdx.x * (BIN_NT * BIN_PPT);
+    uint32_t mk[BIN_PPT];
+#pragma unroll
+    for (int u = 0; u < BIN_PPT; ++u) {
+        const int i = base + u * BIN_NT + threadIdx.x;
+        mk[u] = 0u;
+        if (i < n) {
+            mk[u] = mixed_key(pts[i], find_scene(scene_off, n_scenes, i), g);
+            if (mk[u]) atomicAdd(&lh[shift >= 32 ? 0 : (int)(mk[u] >> shift)], 1);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nslabs; b += BIN_NT) {
+        const int h = lh[b];
+        if (h) lb[b] += atomicAdd(&w.cursor[b], h);
+        lh[b] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < BIN_PPT; ++u) {
+        const int i = base + u * BIN_NT + threadIdx.x;
+        if (mk[u]) {
+            const int s = shift >= 32 ? 0 : (int)(mk[u] >> shift);
+            const int pos = lb[s] + atomicAdd(&lh[s], 1);
+            w.sidx[pos] = i;
+            w.smix[pos] = mk[u];
+        }
+    }
+}
+
+// ---- K3: one workgroup per slab: open-addressing table of the slab's cells -> first index / count per cell, then the
+// cell's points are bucketed contiguously (exclusive scan of the counts over the table slots) so that the slot of a
+// point = number of smaller indices in its bucket is a run of independent LDS reads (no pointer chasing).
+// G = false: arrays in LDS;  G = true: the same arrays in global memory (a slab with more than SLAB_CAP points: only
+// inputs with ~thousands of points in single cells get there; bounded, slow, exact).
+template <bool G>
+__device__ __forceinline__ void slab_rank(int p0, int np, int T, const Ws &w, int32_t *bucket, uint32_t *t_key, int32_t *t_cnt,
+                                          int32_t *t_first, int32_t *t_start, int ts, int *wave_tot) {
+    const int tid = threadIdx.x;
+    const uint32_t tmask = (uint32_t)ts - 1u;
+    for (int x = tid; x < ts; x += SLAB_NT) { t_key[x] = 0u; t_cnt[x] = 0; t_first[x] = 0x7fffffff; }
+    if (G) __threadfence();
+    __syncthreads();
+    // insert: claim / find the cell's slot, count, first index
+    for (int j = tid; j < np; j += SLAB_NT) {
+        const int idx = w.sidx[p0 + j];
+        const uint32_t m = w.smix[p0 + j];
+        uint32_t h = m & tmask;
+        while (true) {
+            const uint32_t prev = atomicCAS(&t_key[h], 0u, m);
+            if (prev == 0u || prev == m) break;
+            h = (h + 1u) & tmask;
+        }
+        atomicMin(&t_first[h], idx);
+        atomicAdd(&t_cnt[h], 1);
+    }
+    if (G) __threadfence();
+    __syncthreads();
+    // bucket starts: exclusive scan of the counts over the table slots (thread t owns `per` consecutive slots)
+    const int per = (ts + SLAB_NT - 1) / SLAB_NT;
+    int c = 0;
+    for (int k = 0; k < per; ++k) {
+        const int x = tid * per + k;
+        if (x < ts) c += t_cnt[x];
+    }
+    int tot;
+    int ex = block_excl_scan(c, wave_tot, SLAB_NT / 64, tot);
+    for (int k = 0; k < per; ++k) {
+        const int x = tid * per + k;
+        if (x < ts) { t_start[x] = ex; ex += t_cnt[x]; }
+    }
+    if (G) __threadfence();
+    __syncthreads();
+    // fill: t_start doubles as the cursor (afterwards t_start[h] = end of the bucket)
+    for (int j = tid; j < np; j += SLAB_NT) {
+        const int idx = w.sidx[p0 + j];
+        const uint32_t m = w.smix[p0 + j];
+        uint32_t h = m & tmask;
+        while (t_key[h] != m) h = (h + 1u) & tmask;
+        if (t_cnt[h] > 1) bucket[atomicAdd(&t_start[h], 1)] = idx;
+    }
+    if (G) __threadfence();
+    __syncthreads();
+    for (int j = tid; j < np; j += SLAB_NT) {
+        const int idx = w.sidx[p0 + j];
+        const uint32_t m = w.smix[p0 + j];
+        uint32_t h = m & tmask;
+        while (t_key[h] != m) h = (h + 1u) & tmask;
+        const int f = t_first[h], cnt = t_cnt[h];
+        if (idx == f) {
+            w.fb[idx] = (uint8_t)(cnt < T ? cnt : T);
+        } else {
+            const int32_t *b = bucket + (t_start[h] - cnt);
+            int r = 0;
+            for (int k = 0; k < cnt && r < T; k += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k + u < cnt) r += (b[k + u] < idx);
+            }
+            w.fb[idx] = 0;
+            w.rec[idx] = make_int2(f, r);          // r >= T: the point is not stored (only "r < T" is used)
+        }
+    }
+}
+
+__global__ void __launch_bounds__(SLAB_NT) k_slab(int T, Ws w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int wave_tot[SLAB_NT / 64];
+    const int s = blockIdx.x;
+    const int p0 = w.gstart[s], np = w.gstart[s + 1] - p0;
+    if (np == 0) return;
+    if (np <= SLAB_CAP) {
+        int32_t *bucket = reinterpret_cast<int32_t *>(smem);
+        uint32_t *t_key = reinterpret_cast<uint32_t *>(bucket + SLAB_CAP);
+        int32_t *t_cnt = reinterpret_cast<int32_t *>(t_key + SLAB_TS);
+        int32_t *t_first = t_cnt + SLAB_TS, *t_start = t_first + SLAB_TS;
+        int ts = 64;
+        while (ts < 2 * np) ts <<= 1;
+        slab_rank<false>(p0, np, T, w, bucket, t_key, t_cnt, t_first, t_start, ts, wave_tot);
+    } else {
+        int ts = 64;
+        while (ts < np) ts <<= 1;            // ts < 2 np: the slab's range [2 p0, 2 p0 + 2 np) of the global tables
+        slab_rank<true>(p0, np, T, w, w.g_bucket + p0, w.g_key + 2 * (int64_t)p0, w.g_cnt + 2 * (int64_t)p0,
+                        w.g_first + 2 * (int64_t)p0, w.g_start + 2 * (int64_t)p0, ts, wave_tot);
+    }
+}
+
+// ---- K4: flag bytes -> 64-point words; per word the popcount prefix INSIDE its 4096-point block, per block the total.
+// (A single-workgroup scan over all flag bytes was tried first: one CU streams ~16 GB/s, 34 us for 524 KB.)
+constexpr int WORDS_NT = 256;
+constexpr int WORDS_PTS = WORDS_NT * 16;          // 4096 points = 64 words per block
+constexpr int MAX_KB = 2048;                      // blocks of 4096 points (n <= 8 M)
+
+__global__ void __launch_bounds__(WORDS_NT) k_words(int n, Ws w) {
+    __shared__ int lcnt[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t base = (int64_t)blockIdx.x * WORDS_PTS + tid * 16;
+    const uint4 v = base < n ? *reinterpret_cast<const uint4 *>(w.fb + base) : make_uint4(0u, 0u, 0u, 0u);
+    // flag bytes are <= 127 (T <= 127): +0x7f sets a byte's top bit iff the byte is nonzero, no carries between
+    // bytes; the multiply gathers the four top bits into one nibble
+    const uint32_t x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t nz = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t y = ((x[k] + 0x7f7f7f7fu) & 0x80808080u) >> 7;
+        nz |= ((y * 0x01020408u) >> 24) << (4 * k);
+    }
+    const int64_t left = (int64_t)n - base;       // bytes past n are not flags
+    if (left < 16) nz = left <= 0 ? 0u : (nz & ((1u << left) - 1u));
+    unsigned long long word = (unsigned long long)nz << (16 * (lane & 3));
+    word |= __shfl_xor(word, 1);
+    word |= __shfl_xor(word, 2);
+    const int nwords = (n + 63) >> 6;
+    const int wl = tid >> 2, wg = blockIdx.x * 64 + wl;
+    if ((lane & 3) == 0) {
+        lcnt[wl] = __popcll(word);
+        if (wg < nwords) w.fmask[wg] = word;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int c = lcnt[tid];
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (tid >= o) incl += t;
+        }
+        const int wi = blockIdx.x * 64 + tid;
+        if (wi < nwords) w.wloc[wi] = incl - c;
+        if (tid == 63) w.btot[blockIdx.x] = incl;
+    }
+}
+
+__device__ __forceinline__ int popc_below(unsigned long long m, int bit) {
+    return __popcll(m & (bit == 0 ? 0ull : (~0ull >> (64 - bit))));
+}
+
+// floor(a / d) for 0 <= a < 2^23, d >= 1
+__device__ __forceinline__ int fdiv(int a, int d, float rd) {
+    int q = (int)((float)a * rd);
+    int r = a - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+
+// ---- K5: placement in input order.  A wave = 64 consecutive points = one flag word.
+// Prologue (every block, a few hundred L2-resident values): exclusive scan of the per-block totals, first-rank at the
+// scene starts, per-scene output offsets with the max_voxels cap; block 0 publishes scene_voxel_off.
+constexpr int PLACE_NT = 1024;
+constexpr int MAX_SCENES = 1024;
+
+__global__ void __launch_bounds__(PLACE_NT) k_place(const float4 *__restrict__ pts, int n, Geom g, int n_scenes, int T, int max_voxels,
+                                                    const int32_t *__restrict__ scene_off, Ws w, float4 *__restrict__ voxels,
+                                                    int4 *__restrict__ coords_bzyx, int32_t *__restrict__ num_pts,
+                                                    int32_t *__restrict__ scene_voxel_off) {
+    __shared__ float4 l_pt[PLACE_NT / 64][64];
+    __shared__ int l_np[PLACE_NT / 64][64];
+    __shared__ int bpre[MAX_KB + 2];
+    __shared__ int l_sfr[MAX_SCENES + 2], l_svo[MAX_SCENES + 2];
+    __shared__ int wave_tot[PLACE_NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nwords = (n + 63) >> 6;
+    const int nkb = (n + WORDS_PTS - 1) / WORDS_PTS;
+    // my point first: its loads fly while the prologue runs
+    const int i = blockIdx.x * PLACE_NT + tid;
+    const bool live = i < n;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    int fbv = 0;
+    if (live) { p = pts[i]; fbv = w.fb[i]; }
+    {   // exclusive scan of btot[0..nkb): two entries per thread
+        const int a0 = 2 * tid < nkb ? w.btot[2 * tid] : 0, a1 = 2 * tid + 1 < nkb ? w.btot[2 * tid + 1] : 0;
+        int tot;
+        const int ex = block_excl_scan(a0 + a1, wave_tot, PLACE_NT / 64, tot);
+        if (2 * tid <= nkb) bpre[2 * tid] = ex;
+        if (2 * tid + 1 <= nkb) bpre[2 * tid + 1] = ex + a0;
+        __syncthreads();
+        for (int s = tid; s <= n_scenes; s += PLACE_NT) {
+            const int si = scene_off[s], wi = si >> 6;
+            l_sfr[s] = wi < nwords ? bpre[wi >> 6] + w.wloc[wi] + popc_below(w.fmask[wi], si & 63) : tot;
+        }
+        __syncthreads();
+        int running = 0;
+        for (int s0 = 0; s0 < n_scenes; s0 += PLACE_NT) {
+            const int s = s0 + tid;
+            int t = 0;
+            if (s < n_scenes) { t = l_sfr[s + 1] - l_sfr[s]; t = t < max_voxels ? t : max_voxels; }
+            int ct;
+            const int e2 = block_excl_scan(t, wave_tot, PLACE_NT / 64, ct);
+            if (s < n_scenes) l_svo[s] = running + e2;
+            running += ct;
+        }
+        if (tid == 0) l_svo[n_scenes] = running;
+        __syncthreads();
+        if (blockIdx.x == 0)
+            for (int s = tid; s <= n_scenes; s += PLACE_NT) scene_voxel_off[s] = l_svo[s];
+    }
+    int s = 0, cc[3] = {0, 0, 0};
+    bool inr = false;
+    if (live) {
+        s = find_scene(scene_off, n_scenes, i);
+        inr = cell_of(p.x, p.y, p.z, g, cc);
+    }
+    const bool first = fbv > 0;
+    const unsigned long long fm = __ballot(first);
+    int wi = (blockIdx.x * PLACE_NT + wv * 64) >> 6;                 // this wave's flag word (wave-uniform)
+    const int wbase = wi < nwords ? bpre[wi >> 6] + w.wloc[wi] : 0;   // waves past the end hold no live lane
+    const int sbase = l_sfr[s], vbase = l_svo[s];
+    const int rs = wbase + popc_below(fm, lane) - sbase;              // rank of my cell among its scene's cells
+    const bool kept = first && rs < max_voxels;
+    const unsigned long long km = __ballot(kept);
+    const int nk = __popcll(km);
+    const int cpos = popc_below(km, lane);
+    const int v = vbase + rs;
+    if (kept) {
+        l_pt[wv][cpos] = p;
+        l_np[wv][cpos] = fbv;
+        num_pts[v] = fbv;
+        coords_bzyx[v] = make_int4(s, cc[2], cc[1], cc[0]);
+    }
+    __syncthreads();
+    if (nk) {
+        const int v0 = __shfl(v, __builtin_ctzll(km));                // kept first points of a wave own consecutive rows
+        float4 *dst = voxels + (int64_t)v0 * T;
+        const float rT = 1.0f / (float)T;
+        const int total = nk * T;
+        for (int e = lane; e < total; e += 64) {
+            const int row = fdiv(e, T, rT), slot = e - row * T;
+            if (slot == 0) dst[e] = l_pt[wv][row];
+            else if (slot >= l_np[wv][row]) dst[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    // non-first points of multi-point cells: scattered 16-byte stores into their cell's row
+    if (live && inr && !first) {
+        const int2 fr = w.rec[i];
+        if (fr.y < T) {
+            const int f = fr.x, fw = f >> 6;
+            const int rf = bpre[fw >> 6] + w.wloc[fw] + popc_below(w.fmask[fw], f & 63) - sbase;
+            if (rf < max_voxels) voxels[(int64_t)(vbase + rf) * T + fr.y] = p;
+        }
+    }
+}
+
+static int ilog2_ceil(int64_t x) {
+    int l = 0;
+    while ((1ll << l) < x) ++l;
+    return l;
+}
+
+}  // namespace vh
+
+size_t lvq_hashed_hard_workspace_bytes(int64_t n, int n_scenes) {
+    vh::SizerAdapter a;
+    vh::Ws w;
+    vh::layout(a, w, n, n_scenes);
+    return a.s.total();
+}
+
+// `continue` cap semantics, C == 4 payloads, T <= 127, key space < 2^31; anything else -> LVQ_EUNSUPPORTED
+int lvq_hashed_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n, int n_scenes, int c, const float *range_host,
+                             const float *vsize_host, const int32_t *grid_host, int max_pts, int max_voxels, float *voxels,
+                             int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes,
+                             hipStream_t st) {
+    using namespace vh;
+    if (c != 4 || max_pts > 127 || (((uintptr_t)pts | (uintptr_t)voxels | (uintptr_t)coords_bzyx) & 15)) return LVQ_EUNSUPPORTED;
+    const int64_t keyspace = (int64_t)n_scenes * grid_host[0] * grid_host[1] * grid_host[2];
+    if (keyspace <= 0 || keyspace >= (1ll << 31) - 1 || n > (int64_t)MAX_KB * WORDS_PTS || n_scenes > MAX_SCENES)
+        return LVQ_EUNSUPPORTED;
+    // slab count: power of two, ~n/512 .. n/1024 points each for big inputs, never below 256 points on average
+    int64_t mean = n / 512;
+    mean = mean < 256 ? 256 : (mean > 1024 ? 1024 : mean);
+    int lg = ilog2_ceil(lvq_cdiv(n, mean));
+    if ((1 << lg) > MAX_SLABS) {
+        lg = ilog2_ceil(MAX_SLABS);
+        if (n / MAX_SLABS > SLAB_CAP * 3 / 4) return LVQ_EUNSUPPORTED;
+    }
+    const int nslabs = 1 << lg, shift = 32 - lg;
+    LvqArena arena(ws, ws_bytes);
+    Ws w;
+    layout(arena, w, n, n_scenes);
+    if (!arena.ok) return LVQ_EWORKSPACE;
+    Geom g;
+    for (int j = 0; j < 3; ++j) { g.lo[j] = range_host[j]; g.vs[j] = vsize_host[j]; g.grid[j] = grid_host[j]; }
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void *)k_slab, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr = true;
+    }
+    const unsigned nb = (unsigned)lvq_cdiv(n, BIN_NT * BIN_PPT);
+    const float4 *p4 = reinterpret_cast<const float4 *>(pts);
+    hipMemsetAsync(w.ghist, 0, sizeof(int32_t) * 2 * (MAX_SLABS + 64), st);
+    hipLaunchKernelGGL(k_hist, dim3(nb), dim3(BIN_NT), sizeof(int32_t) * nslabs, st, p4, (int)n, g, n_scenes, shift, nslabs, scene_off, w);
+    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(BIN_NT), 2 * sizeof(int32_t) * nslabs, st, p4, (int)n, g, n_scenes, shift, nslabs,
+                       scene_off, w);
+    const size_t slab_lds = sizeof(int32_t) * SLAB_CAP + 4 * sizeof(int32_t) * SLAB_TS;
+    hipLaunchKernelGGL(k_slab, dim3(nslabs), dim3(SLAB_NT), slab_lds, st, max_pts, w);
+    hipLaunchKernelGGL(k_words, dim3((unsigned)lvq_cdiv(n, WORDS_PTS)), dim3(WORDS_NT), 0, st, (int)n, w);
+    hipLaunchKernelGGL(k_place, dim3((unsigned)lvq_cdiv(n, PLACE_NT)), dim3(PLACE_NT), 0, st, p4, (int)n, g, n_scenes, max_pts, max_voxels,
+                       scene_off, w, reinterpret_cast<float4 *>(voxels), reinterpret_cast<int4 *>(coords_bzyx), num_pts,
+                       scene_voxel_off);
+    return lvq_launch_status();
+}

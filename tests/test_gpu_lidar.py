@@ -68,8 +68,15 @@ HARD_CASES = [
 ]
 
 
+# default = hash-balanced slabs (voxel_hashed.hip); the two older implementations stay reachable and are held to the same oracle
+VOXEL_PATHS = {"hashed": None, "binned": "LVQ_VOXEL_BINNED", "legacy": "LVQ_VOXEL_LEGACY"}
+
+
+@pytest.mark.parametrize("path", list(VOXEL_PATHS))
 @pytest.mark.parametrize("dist,n,seed,vs,T,mv,brk", HARD_CASES)
-def test_hard_voxelizer_vs_oracle(dist, n, seed, vs, T, mv, brk):
+def test_hard_voxelizer_vs_oracle(dist, n, seed, vs, T, mv, brk, path, monkeypatch):
+    if VOXEL_PATHS[path]:
+        monkeypatch.setenv(VOXEL_PATHS[path], "1")
     pts = masked(dist, n, seed)
     ov, oc, on = LO.VoxelGenerator(vs, RNG, 4, T, mv, break_on_cap=brk).generate(pts)
     gv, gc, gn = L().VoxelGeneratorWrapper(vs, RNG, 4, T, mv, break_on_cap=brk).generate(pts)
@@ -98,6 +105,46 @@ def test_hard_voxelizer_5_features_and_batch():
     ov, oc, on = LO.VoxelGenerator(synth.VOXEL_01, RNG, 5, 10, 60000).generate(p5)
     gv, gc, gn = lid.VoxelGeneratorWrapper(synth.VOXEL_01, RNG, 5, 10, 60000).generate(p5)
     assert np.array_equal(gc, oc) and np.array_equal(gn, on) and np.array_equal(gv, ov)
+
+
+@pytest.mark.parametrize("T,mv", [(10, 1500), (127, 300), (128, 300), (5, 100000)])
+def test_hard_voxelizer_batch_caps_and_unmasked_points(T, mv):
+    """A ragged 5-scene batch whose scene boundaries fall inside 64-point flag words, with out-of-range points left in
+    (the wrapper is also called on unmasked clouds), per-scene max_voxels hit in some scenes and not in others, T at the
+    hashed path's limit (127) and beyond it (128 -> slab-binned fallback): == per-scene oracle results concatenated."""
+    lid = L()
+    sizes = [3001, 77, 0, 9000, 1]
+    scenes = [synth.scene_points("C" if k % 2 == 0 else "U", sz, 200 + k) for k, sz in enumerate(sizes)]
+    for sc in scenes:
+        if len(sc) > 50:
+            sc[::7, 0] += 120.0                          # outside the grid: dropped by the voxeliser itself
+    gen = lid.VoxelGeneratorWrapper(synth.VOXEL_PILLAR, RNG, 4, T, mv)
+    bd = lid.voxelize_batch(gen, [torch.from_numpy(sc).to(DEV) for sc in scenes])
+    exp = []
+    for sc in scenes:
+        v, c, k = LO.VoxelGenerator(synth.VOXEL_PILLAR, RNG, 4, T, mv).generate(sc)
+        exp.append(dict(voxels=v, voxel_coords=c, voxel_num_points=k, points=sc))
+    ob = LO.collate_batch(exp)
+    assert np.array_equal(bd["voxel_coords"].cpu().numpy(), ob["voxel_coords"])
+    assert np.array_equal(bd["voxel_num_points"].cpu().numpy(), ob["voxel_num_points"])
+    assert np.array_equal(bd["voxels"].cpu().numpy().view(np.uint32), ob["voxels"].view(np.uint32))
+
+
+def test_hard_voxelizer_hot_cells_among_ordinary_ones():
+    """A few cells with thousands of points (long per-cell lists in the slab table) inside an ordinary cloud."""
+    rng = np.random.default_rng(9)
+    base = masked("C", 30000, 77)
+    hot = []
+    for cx, cy in [(3.03, -7.01), (-20.55, 11.11), (40.0, 40.0)]:
+        k = 1500
+        hot.append(np.concatenate((cx + rng.uniform(0.0, 0.09, (k, 1)), cy + rng.uniform(0.0, 0.09, (k, 1)),
+                                   rng.uniform(-1.19, -1.01, (k, 1)), rng.random((k, 1))), axis=1).astype(np.float32))
+    pts = np.concatenate([base] + hot)
+    pts = pts[rng.permutation(len(pts))]
+    for vs, T in [(synth.VOXEL_01, 10), (synth.VOXEL_PILLAR, 20)]:
+        ov, oc, on = LO.VoxelGenerator(vs, RNG, 4, T, 60000).generate(pts)
+        gv, gc, gn = L().VoxelGeneratorWrapper(vs, RNG, 4, T, 60000).generate(pts)
+        assert np.array_equal(gc, oc) and np.array_equal(gn, on) and np.array_equal(gv.view(np.uint32), ov.view(np.uint32))
 
 
 def test_hard_voxelizer_all_points_one_voxel():
