@@ -15,15 +15,17 @@
 //     statistically balanced (no hot slabs), a power-of-two count of ~1000-point slabs is enough (4x fewer global
 //     atomics), and ONE slab kernel serves every slab: an LDS open-addressing table (CAS insert, per-cell intrusive
 //     list, atomicMin first index, count) -> O(points) LDS work instead of the O(n_s^2) compare loop.
-//   * the slab scan is folded into the scatter kernel (every block rescans the <= 8192-entry histogram in LDS);
-//     flags -> words keeps only block-local prefixes (k_words); the scan over the per-block totals, the first-rank at
+//   * balanced slabs need no histogram pass: every slab owns a fixed 2048-entry region (mean fill <= 1024) that is
+//     filled in ONE binning pass; the rare entries that do not fit go to a shared overflow list and their slab is ranked
+//     on global arrays (it would not fit LDS anyway).
+//   * flags -> words keeps only block-local prefixes (k_words); the scan over the per-block totals, the first-rank at
 //     the scene starts and the capped scene offsets are recomputed in the prologue of every placement block
 //     (a few hundred L2-resident values) -- no single-workgroup scan kernels are left.
 //   * placement runs in INPUT order: consecutive first points own consecutive output rows (that is what first-appearance
 //     order means), so a wave stages its first points in LDS and streams rows*T*16 contiguous bytes with full 1 KB
 //     wave stores (zero padding included); only non-first points (multi-point cells) issue scattered 16-byte stores.
 //     coords / num_points leave as dense stores, cell coordinates are recomputed from the point (no key decode).
-//   5 kernels + 1 memset.  Unsupported shapes (C != 4, T > 127, key space >= 2^31, n > 8 M, > 1024 scenes, `break` cap) -> LVQ_EUNSUPPORTED
+//   4 kernels + 1 memset (k_bin, k_slab, k_words, k_place).  Unsupported shapes (C != 4, T > 127, key space >= 2^31, n > 8 M, > 1024 scenes, `break` cap) -> LVQ_EUNSUPPORTED
 //   and the caller falls back to voxel_binned.hip / the hash kernels in voxel.hip.
 #include "common.h"
 
@@ -43,32 +45,48 @@ constexpr int SLAB_CAP = 2048;        // points of a slab ranked in LDS (larger 
 constexpr int SLAB_TS = 2 * SLAB_CAP; // table slots in LDS
 
 struct Ws {
-    int32_t *ghist, *cursor;          // [MAX_SLABS+1] each, contiguous (one memset)
-    int32_t *gstart;                  // [MAX_SLABS+2]
-    int32_t *sidx;                    // [n] original index, grouped by slab
-    uint32_t *smix;                   // [n] mixed key (equal mix <=> equal cell)
+    int32_t *cursor;                  // [MAX_SLABS] points per slab, then ovf_count, galloc: one memset
+    int32_t *ovf_count, *galloc;
+    int32_t *sidx;                    // [nslabs * SLAB_CAP] original index, slab s owns [s * SLAB_CAP, (s+1) * SLAB_CAP)
+    uint32_t *smix;                   // same layout: mixed key (equal mix <=> equal cell)
+    int32_t *ovf_idx;                 // [n] entries that did not fit their slab's region
+    uint32_t *ovf_mix;
     uint8_t *fb;                      // [n+64] by ORIGINAL index: min(count, T) for the first point of a cell, else 0
     int2 *rec;                        // [n]    by ORIGINAL index, non-first points: (first index of the cell, slot)
     uint64_t *fmask;                  // [nwords+1] first-point flags, 64 points per word
     int32_t *wloc;                    // [nwords+2] exclusive popcount prefix of a word inside its 4096-point block
     int32_t *btot;                    // [MAX_KB+2] first points per 4096-point block
-    int32_t *g_bucket;                // [n]      oversize slabs: global stand-ins for the LDS arrays
+    int32_t *g_idx;                   // [n]      oversize slabs: contiguous point lists + global stand-ins for the LDS arrays
+    uint32_t *g_mix;
+    int32_t *g_bucket;                // [n]
     uint32_t *g_key;                  // [2n+64]
     int32_t *g_cnt, *g_first, *g_start;
 };
 
+// power-of-two slab count with a mean fill in (512, 1024] points (regions hold SLAB_CAP = 2048)
+static int slab_count(int64_t n) {
+    int lg = 0;
+    while (((int64_t)1024 << lg) < n) ++lg;
+    return 1 << lg;
+}
+
 template <typename A> void layout(A &a, Ws &w, int64_t n, int n_scenes) {
     const int64_t nwords = (n + 63) / 64;
-    w.ghist = a.template take<int32_t>(2 * (MAX_SLABS + 64));
-    w.cursor = w.ghist ? w.ghist + MAX_SLABS + 64 : nullptr;
-    w.gstart = a.template take<int32_t>(MAX_SLABS + 2);
-    w.sidx = a.template take<int32_t>(n + 1);
-    w.smix = a.template take<uint32_t>(n + 1);
+    const int64_t region = (int64_t)slab_count(n) * SLAB_CAP;
+    w.cursor = a.template take<int32_t>(MAX_SLABS + 64);
+    w.ovf_count = w.cursor ? w.cursor + MAX_SLABS : nullptr;
+    w.galloc = w.cursor ? w.cursor + MAX_SLABS + 1 : nullptr;
+    w.sidx = a.template take<int32_t>(region + 1);
+    w.smix = a.template take<uint32_t>(region + 1);
+    w.ovf_idx = a.template take<int32_t>(n + 1);
+    w.ovf_mix = a.template take<uint32_t>(n + 1);
     w.fb = a.template take<uint8_t>(n + 64);
     w.rec = a.template take<int2>(n + 1);
     w.fmask = a.template take<uint64_t>(nwords + 1);
     w.wloc = a.template take<int32_t>(nwords + 2);
     w.btot = a.template take<int32_t>(4096);
+    w.g_idx = a.template take<int32_t>(n + 1);
+    w.g_mix = a.template take<uint32_t>(n + 1);
     w.g_bucket = a.template take<int32_t>(n + 1);
     w.g_key = a.template take<uint32_t>(2 * n + 64);
     w.g_cnt = a.template take<int32_t>(2 * n + 64);
@@ -143,69 +161,35 @@ __device__ __forceinline__ int block_excl_scan(int v, int *wave_tot, int nwaves,
     return wbase + incl - v;
 }
 
-// ---- K1: per-slab histogram in LDS; points outside the grid get their flag byte cleared here ----
-__global__ void __launch_bounds__(BIN_NT) k_hist(const float4 *__restrict__ pts, int n, Geom g, int n_scenes, int shift, int nslabs,
-                                                 const int32_t *__restrict__ scene_off, Ws w) {
-    extern __shared__ int32_t lh[];
+// ---- K1: single-pass binning.  Hash-balanced slabs need no histogram pass: every slab owns a fixed region of SLAB_CAP
+// entries (mean fill <= 1024); a block counts its points per slab in LDS (the LDS atomic's return value is the point's
+// rank inside the block's run), reserves the runs with one global atomic per (block, slab) and writes (index, mixed key).
+// Entries that do not fit their region go to one shared overflow list -- their slab cannot be ranked in LDS anyway.
+// Points outside the grid get their flag byte cleared here.
+__global__ void __launch_bounds__(BIN_NT) k_bin(const float4 *__restrict__ pts, int n, Geom g, int n_scenes, int shift, int nslabs,
+                                                const int32_t *__restrict__ scene_off, Ws w) {
+    extern __shared__ int32_t lds[];
+    int32_t *lh = lds, *lb = lds + nslabs;
     for (int b = threadIdx.x; b < nslabs; b += BIN_NT) lh[b] = 0;
     __syncthreads();
     const int base = blockIdx.x * (BIN_NT * BIN_PPT);
-#pragma unroll
-    for (int u = 0; u < BIN_PPT; ++u) {
-        const int i = base + u * BIN_NT + threadIdx.x;
-        if (i < n) {
-            const uint32_t m = mixed_key(pts[i], find_scene(scene_off, n_scenes, i), g);
-            if (m) atomicAdd(&lh[shift >= 32 ? 0 : (int)(m >> shift)], 1);
-            else w.fb[i] = 0;
-        }
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < nslabs; b += BIN_NT)
-        if (lh[b]) atomicAdd(&w.ghist[b], lh[b]);
-}
-
-// ---- K2: scatter (original index, mixed key) grouped by slab; the slab scan is redone per block in LDS ----
-__global__ void __launch_bounds__(BIN_NT) k_scatter(const float4 *__restrict__ pts, int n, Geom g, int n_scenes, int shift, int nslabs,
-                                                    const int32_t *__restrict__ scene_off, Ws w) {
-    extern __shared__ int32_t lds[];
-    __shared__ int wave_tot[BIN_NT / 64];
-    int32_t *lh = lds, *lb = lds + nslabs;
-    // exclusive scan of the global histogram: thread t owns `per` consecutive slabs
-    const int per = (nslabs + BIN_NT - 1) / BIN_NT;
-    int c = 0;
-    for (int j = 0; j < per; ++j) {
-        const int b = threadIdx.x * per + j;
-        if (b < nslabs) c += w.ghist[b];
-    }
-    int tot;
-    int ex = block_excl_scan(c, wave_tot, BIN_NT / 64, tot);
-    for (int j = 0; j < per; ++j) {
-        const int b = threadIdx.x * per + j;
-        if (b < nslabs) {
-            lb[b] = ex;
-            lh[b] = 0;
-            if (blockIdx.x == 0) w.gstart[b] = ex;
-            ex += w.ghist[b];
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) w.gstart[nslabs] = tot;
-    __syncthreads();
-    const int base = blockIdx.x * (BIN_NT * BIN_PPT);
     uint32_t mk[BIN_PPT];
+    int rk[BIN_PPT];
 #pragma unroll
     for (int u = 0; u < BIN_PPT; ++u) {
         const int i = base + u * BIN_NT + threadIdx.x;
         mk[u] = 0u;
+        rk[u] = 0;
         if (i < n) {
             mk[u] = mixed_key(pts[i], find_scene(scene_off, n_scenes, i), g);
-            if (mk[u]) atomicAdd(&lh[shift >= 32 ? 0 : (int)(mk[u] >> shift)], 1);
+            if (mk[u]) rk[u] = atomicAdd(&lh[shift >= 32 ? 0 : (int)(mk[u] >> shift)], 1);
+            else w.fb[i] = 0;
         }
     }
     __syncthreads();
     for (int b = threadIdx.x; b < nslabs; b += BIN_NT) {
         const int h = lh[b];
-        if (h) lb[b] += atomicAdd(&w.cursor[b], h);
-        lh[b] = 0;
+        if (h) lb[b] = atomicAdd(&w.cursor[b], h);
     }
     __syncthreads();
 #pragma unroll
@@ -213,42 +197,69 @@ __global__ void __launch_bounds__(BIN_NT) k_scatter(const float4 *__restrict__ p
         const int i = base + u * BIN_NT + threadIdx.x;
         if (mk[u]) {
             const int s = shift >= 32 ? 0 : (int)(mk[u] >> shift);
-            const int pos = lb[s] + atomicAdd(&lh[s], 1);
-            w.sidx[pos] = i;
-            w.smix[pos] = mk[u];
+            const int pos = lb[s] + rk[u];
+            if (pos < SLAB_CAP) {
+                w.sidx[(int64_t)s * SLAB_CAP + pos] = i;
+                w.smix[(int64_t)s * SLAB_CAP + pos] = mk[u];
+            } else {
+                const int o = atomicAdd(w.ovf_count, 1);
+                w.ovf_idx[o] = i;
+                w.ovf_mix[o] = mk[u];
+            }
         }
     }
 }
 
-// ---- K3: one workgroup per slab: open-addressing table of the slab's cells -> first index / count per cell, then the
+// ---- K2: one workgroup per slab: open-addressing table of the slab's cells -> first index / count per cell, then the
 // cell's points are bucketed contiguously (exclusive scan of the counts over the table slots) so that the slot of a
-// point = number of smaller indices in its bucket is a run of independent LDS reads (no pointer chasing).
-// G = false: arrays in LDS;  G = true: the same arrays in global memory (a slab with more than SLAB_CAP points: only
-// inputs with ~thousands of points in single cells get there; bounded, slow, exact).
-template <bool G>
-__device__ __forceinline__ void slab_rank(int p0, int np, int T, const Ws &w, int32_t *bucket, uint32_t *t_key, int32_t *t_cnt,
-                                          int32_t *t_first, int32_t *t_start, int ts, int *wave_tot) {
+// point = number of smaller indices in its bucket is a run of independent reads (no pointer chasing).
+__device__ __forceinline__ void write_rank(const Ws &w, int T, int idx, int f, int cnt, const int32_t *b) {
+    if (idx == f) {
+        w.fb[idx] = (uint8_t)(cnt < T ? cnt : T);
+    } else {
+        int r = 0;
+        for (int k = 0; k < cnt && r < T; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k + u < cnt) r += (b[k + u] < idx);
+        }
+        w.fb[idx] = 0;
+        w.rec[idx] = make_int2(f, r);          // r >= T: the point is not stored (only "r < T" is used)
+    }
+}
+
+// LDS form (np <= SLAB_CAP): a thread keeps its <= 4 points (index, key, table slot) in registers across the phases
+__device__ __forceinline__ void slab_rank_lds(const int32_t *__restrict__ sidx, const uint32_t *__restrict__ smix, int np, int T,
+                                              const Ws &w, int32_t *bucket, uint32_t *t_key, int32_t *t_cnt, int32_t *t_first,
+                                              int32_t *t_start, int ts, int *wave_tot) {
+    constexpr int PPT = SLAB_CAP / SLAB_NT;
     const int tid = threadIdx.x;
     const uint32_t tmask = (uint32_t)ts - 1u;
-    for (int x = tid; x < ts; x += SLAB_NT) { t_key[x] = 0u; t_cnt[x] = 0; t_first[x] = 0x7fffffff; }
-    if (G) __threadfence();
-    __syncthreads();
-    // insert: claim / find the cell's slot, count, first index
-    for (int j = tid; j < np; j += SLAB_NT) {
-        const int idx = w.sidx[p0 + j];
-        const uint32_t m = w.smix[p0 + j];
-        uint32_t h = m & tmask;
-        while (true) {
-            const uint32_t prev = atomicCAS(&t_key[h], 0u, m);
-            if (prev == 0u || prev == m) break;
-            h = (h + 1u) & tmask;
-        }
-        atomicMin(&t_first[h], idx);
-        atomicAdd(&t_cnt[h], 1);
+    int idx[PPT];
+    uint32_t m[PPT], h[PPT];
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        const int j = tid + u * SLAB_NT;
+        idx[u] = j < np ? sidx[j] : 0;
+        m[u] = j < np ? smix[j] : 0u;
     }
-    if (G) __threadfence();
+    for (int x = tid; x < ts; x += SLAB_NT) { t_key[x] = 0u; t_cnt[x] = 0; t_first[x] = 0x7fffffff; }
     __syncthreads();
-    // bucket starts: exclusive scan of the counts over the table slots (thread t owns `per` consecutive slots)
+#pragma unroll
+    for (int u = 0; u < PPT; ++u) {
+        if (m[u]) {
+            uint32_t hh = m[u] & tmask;
+            while (true) {
+                const uint32_t prev = atomicCAS(&t_key[hh], 0u, m[u]);
+                if (prev == 0u || prev == m[u]) break;
+                hh = (hh + 1u) & tmask;
+            }
+            h[u] = hh;
+            atomicMin(&t_first[hh], idx[u]);
+            atomicAdd(&t_cnt[hh], 1);
+        }
+    }
+    __syncthreads();
     const int per = (ts + SLAB_NT - 1) / SLAB_NT;
     int c = 0;
     for (int k = 0; k < per; ++k) {
@@ -261,46 +272,83 @@ __device__ __forceinline__ void slab_rank(int p0, int np, int T, const Ws &w, in
         const int x = tid * per + k;
         if (x < ts) { t_start[x] = ex; ex += t_cnt[x]; }
     }
-    if (G) __threadfence();
     __syncthreads();
-    // fill: t_start doubles as the cursor (afterwards t_start[h] = end of the bucket)
-    for (int j = tid; j < np; j += SLAB_NT) {
-        const int idx = w.sidx[p0 + j];
-        const uint32_t m = w.smix[p0 + j];
-        uint32_t h = m & tmask;
-        while (t_key[h] != m) h = (h + 1u) & tmask;
-        if (t_cnt[h] > 1) bucket[atomicAdd(&t_start[h], 1)] = idx;
-    }
-    if (G) __threadfence();
-    __syncthreads();
-    for (int j = tid; j < np; j += SLAB_NT) {
-        const int idx = w.sidx[p0 + j];
-        const uint32_t m = w.smix[p0 + j];
-        uint32_t h = m & tmask;
-        while (t_key[h] != m) h = (h + 1u) & tmask;
-        const int f = t_first[h], cnt = t_cnt[h];
-        if (idx == f) {
-            w.fb[idx] = (uint8_t)(cnt < T ? cnt : T);
-        } else {
-            const int32_t *b = bucket + (t_start[h] - cnt);
-            int r = 0;
-            for (int k = 0; k < cnt && r < T; k += 4) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (k + u < cnt) r += (b[k + u] < idx);
-            }
-            w.fb[idx] = 0;
-            w.rec[idx] = make_int2(f, r);          // r >= T: the point is not stored (only "r < T" is used)
+    for (int u = 0; u < PPT; ++u)
+        if (m[u] && t_cnt[h[u]] > 1) bucket[atomicAdd(&t_start[h[u]], 1)] = idx[u];    // t_start doubles as the cursor
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < PPT; ++u)
+        if (m[u]) {
+            const int cnt = t_cnt[h[u]];
+            write_rank(w, T, idx[u], t_first[h[u]], cnt, bucket + (t_start[h[u]] - cnt));
         }
+}
+
+// global form: the same phases on global arrays (a slab with more than SLAB_CAP points: only inputs with ~thousands of
+// points in single cells get there; bounded, slow, exact)
+__device__ __forceinline__ void slab_rank_glob(const int32_t *sidx, const uint32_t *smix, int np, int T, const Ws &w, int32_t *bucket,
+                                               uint32_t *t_key, int32_t *t_cnt, int32_t *t_first, int32_t *t_start, int ts,
+                                               int *wave_tot) {
+    const int tid = threadIdx.x;
+    const uint32_t tmask = (uint32_t)ts - 1u;
+    for (int x = tid; x < ts; x += SLAB_NT) { t_key[x] = 0u; t_cnt[x] = 0; t_first[x] = 0x7fffffff; }
+    __threadfence();
+    __syncthreads();
+    for (int j = tid; j < np; j += SLAB_NT) {
+        const int idx = sidx[j];
+        const uint32_t m = smix[j];
+        uint32_t h = m & tmask;
+        while (true) {
+            const uint32_t prev = atomicCAS(&t_key[h], 0u, m);
+            if (prev == 0u || prev == m) break;
+            h = (h + 1u) & tmask;
+        }
+        atomicMin(&t_first[h], idx);
+        atomicAdd(&t_cnt[h], 1);
+    }
+    __threadfence();
+    __syncthreads();
+    const int per = (ts + SLAB_NT - 1) / SLAB_NT;
+    int c = 0;
+    for (int k = 0; k < per; ++k) {
+        const int x = tid * per + k;
+        if (x < ts) c += t_cnt[x];
+    }
+    int tot;
+    int ex = block_excl_scan(c, wave_tot, SLAB_NT / 64, tot);
+    for (int k = 0; k < per; ++k) {
+        const int x = tid * per + k;
+        if (x < ts) { t_start[x] = ex; ex += t_cnt[x]; }
+    }
+    __threadfence();
+    __syncthreads();
+    for (int j = tid; j < np; j += SLAB_NT) {
+        const uint32_t m = smix[j];
+        uint32_t h = m & tmask;
+        while (t_key[h] != m) h = (h + 1u) & tmask;
+        if (t_cnt[h] > 1) bucket[atomicAdd(&t_start[h], 1)] = sidx[j];
+    }
+    __threadfence();
+    __syncthreads();
+    for (int j = tid; j < np; j += SLAB_NT) {
+        const uint32_t m = smix[j];
+        uint32_t h = m & tmask;
+        while (t_key[h] != m) h = (h + 1u) & tmask;
+        const int cnt = t_cnt[h];
+        write_rank(w, T, sidx[j], t_first[h], cnt, bucket + (t_start[h] - cnt));
     }
 }
 
-__global__ void __launch_bounds__(SLAB_NT) k_slab(int T, Ws w) {
+__global__ void __launch_bounds__(SLAB_NT) k_slab(int T, int shift, Ws w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int wave_tot[SLAB_NT / 64];
-    const int s = blockIdx.x;
-    const int p0 = w.gstart[s], np = w.gstart[s + 1] - p0;
+    __shared__ int l_goff, l_fill;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int np = w.cursor[s];                 // every point of the slab: region entries + its share of the overflow list
     if (np == 0) return;
+    const int32_t *sidx = w.sidx + (int64_t)s * SLAB_CAP;
+    const uint32_t *smix = w.smix + (int64_t)s * SLAB_CAP;
     if (np <= SLAB_CAP) {
         int32_t *bucket = reinterpret_cast<int32_t *>(smem);
         uint32_t *t_key = reinterpret_cast<uint32_t *>(bucket + SLAB_CAP);
@@ -308,12 +356,30 @@ __global__ void __launch_bounds__(SLAB_NT) k_slab(int T, Ws w) {
         int32_t *t_first = t_cnt + SLAB_TS, *t_start = t_first + SLAB_TS;
         int ts = 64;
         while (ts < 2 * np) ts <<= 1;
-        slab_rank<false>(p0, np, T, w, bucket, t_key, t_cnt, t_first, t_start, ts, wave_tot);
+        slab_rank_lds(sidx, smix, np, T, w, bucket, t_key, t_cnt, t_first, t_start, ts, wave_tot);
     } else {
+        // oversize: gather the slab's points (region + matching overflow entries) into a contiguous global list
+        if (tid == 0) { l_goff = atomicAdd(w.galloc, np); l_fill = SLAB_CAP; }
+        __syncthreads();
+        const int64_t goff = l_goff;
+        int32_t *gi = w.g_idx + goff;
+        uint32_t *gm = w.g_mix + goff;
+        for (int j = tid; j < SLAB_CAP; j += SLAB_NT) { gi[j] = sidx[j]; gm[j] = smix[j]; }
+        const int novf = *w.ovf_count;
+        for (int o = tid; o < novf; o += SLAB_NT) {
+            const uint32_t m = w.ovf_mix[o];
+            if ((shift >= 32 ? 0 : (int)(m >> shift)) == s) {
+                const int q = atomicAdd(&l_fill, 1);
+                gi[q] = w.ovf_idx[o];
+                gm[q] = m;
+            }
+        }
+        __threadfence();
+        __syncthreads();
         int ts = 64;
-        while (ts < np) ts <<= 1;            // ts < 2 np: the slab's range [2 p0, 2 p0 + 2 np) of the global tables
-        slab_rank<true>(p0, np, T, w, w.g_bucket + p0, w.g_key + 2 * (int64_t)p0, w.g_cnt + 2 * (int64_t)p0,
-                        w.g_first + 2 * (int64_t)p0, w.g_start + 2 * (int64_t)p0, ts, wave_tot);
+        while (ts < np) ts <<= 1;                // ts < 2 np: tables at [2 goff, 2 goff + 2 np)
+        slab_rank_glob(gi, gm, np, T, w, w.g_bucket + goff, w.g_key + 2 * goff, w.g_cnt + 2 * goff, w.g_first + 2 * goff,
+                       w.g_start + 2 * goff, ts, wave_tot);
     }
 }
 
@@ -473,12 +539,6 @@ __global__ void __launch_bounds__(PLACE_NT) k_place(const float4 *__restrict__ p
     }
 }
 
-static int ilog2_ceil(int64_t x) {
-    int l = 0;
-    while ((1ll << l) < x) ++l;
-    return l;
-}
-
 }  // namespace vh
 
 size_t lvq_hashed_hard_workspace_bytes(int64_t n, int n_scenes) {
@@ -498,15 +558,11 @@ int lvq_hashed_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t
     const int64_t keyspace = (int64_t)n_scenes * grid_host[0] * grid_host[1] * grid_host[2];
     if (keyspace <= 0 || keyspace >= (1ll << 31) - 1 || n > (int64_t)MAX_KB * WORDS_PTS || n_scenes > MAX_SCENES)
         return LVQ_EUNSUPPORTED;
-    // slab count: power of two, ~n/512 .. n/1024 points each for big inputs, never below 256 points on average
-    int64_t mean = n / 512;
-    mean = mean < 256 ? 256 : (mean > 1024 ? 1024 : mean);
-    int lg = ilog2_ceil(lvq_cdiv(n, mean));
-    if ((1 << lg) > MAX_SLABS) {
-        lg = ilog2_ceil(MAX_SLABS);
-        if (n / MAX_SLABS > SLAB_CAP * 3 / 4) return LVQ_EUNSUPPORTED;
-    }
-    const int nslabs = 1 << lg, shift = 32 - lg;
+    const int nslabs = slab_count(n);
+    if (nslabs > MAX_SLABS) return LVQ_EUNSUPPORTED;
+    int lg = 0;
+    while ((1 << lg) < nslabs) ++lg;
+    const int shift = 32 - lg;
     LvqArena arena(ws, ws_bytes);
     Ws w;
     layout(arena, w, n, n_scenes);
@@ -520,12 +576,10 @@ int lvq_hashed_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t
     }
     const unsigned nb = (unsigned)lvq_cdiv(n, BIN_NT * BIN_PPT);
     const float4 *p4 = reinterpret_cast<const float4 *>(pts);
-    hipMemsetAsync(w.ghist, 0, sizeof(int32_t) * 2 * (MAX_SLABS + 64), st);
-    hipLaunchKernelGGL(k_hist, dim3(nb), dim3(BIN_NT), sizeof(int32_t) * nslabs, st, p4, (int)n, g, n_scenes, shift, nslabs, scene_off, w);
-    hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(BIN_NT), 2 * sizeof(int32_t) * nslabs, st, p4, (int)n, g, n_scenes, shift, nslabs,
-                       scene_off, w);
+    hipMemsetAsync(w.cursor, 0, sizeof(int32_t) * (MAX_SLABS + 64), st);
+    hipLaunchKernelGGL(k_bin, dim3(nb), dim3(BIN_NT), 2 * sizeof(int32_t) * nslabs, st, p4, (int)n, g, n_scenes, shift, nslabs, scene_off, w);
     const size_t slab_lds = sizeof(int32_t) * SLAB_CAP + 4 * sizeof(int32_t) * SLAB_TS;
-    hipLaunchKernelGGL(k_slab, dim3(nslabs), dim3(SLAB_NT), slab_lds, st, max_pts, w);
+    hipLaunchKernelGGL(k_slab, dim3(nslabs), dim3(SLAB_NT), slab_lds, st, max_pts, shift, w);
     hipLaunchKernelGGL(k_words, dim3((unsigned)lvq_cdiv(n, WORDS_PTS)), dim3(WORDS_NT), 0, st, (int)n, w);
     hipLaunchKernelGGL(k_place, dim3((unsigned)lvq_cdiv(n, PLACE_NT)), dim3(PLACE_NT), 0, st, p4, (int)n, g, n_scenes, max_pts, max_voxels,
                        scene_off, w, reinterpret_cast<float4 *>(voxels), reinterpret_cast<int4 *>(coords_bzyx), num_pts,

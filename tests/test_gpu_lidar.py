@@ -135,8 +135,8 @@ def test_hard_voxelizer_hot_cells_among_ordinary_ones():
     rng = np.random.default_rng(9)
     base = masked("C", 30000, 77)
     hot = []
-    for cx, cy in [(3.03, -7.01), (-20.55, 11.11), (40.0, 40.0)]:
-        k = 1500
+    # 1500: long bucket inside an LDS-ranked slab; 2600 / 5000: the slab overflows its region -> overflow list + global ranking
+    for (cx, cy), k in zip([(3.03, -7.01), (-20.55, 11.11), (40.0, 40.0)], [1500, 2600, 5000]):
         hot.append(np.concatenate((cx + rng.uniform(0.0, 0.09, (k, 1)), cy + rng.uniform(0.0, 0.09, (k, 1)),
                                    rng.uniform(-1.19, -1.01, (k, 1)), rng.random((k, 1))), axis=1).astype(np.float32))
     pts = np.concatenate([base] + hot)
