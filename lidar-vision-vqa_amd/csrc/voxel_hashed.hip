@@ -13,8 +13,9 @@
 // This file keeps the idea (sort points into LDS-sized groups that hold whole cells, rank inside LDS) and changes:
 //   * slab = top bits of a BIJECTIVE 32-bit mix of the key: every cell still lands in exactly one slab, but slabs are
 //     statistically balanced (no hot slabs), a power-of-two count of ~1000-point slabs is enough (4x fewer global
-//     atomics), and ONE slab kernel serves every slab: an LDS open-addressing table (CAS insert, per-cell intrusive
-//     list, atomicMin first index, count) -> O(points) LDS work instead of the O(n_s^2) compare loop.
+//     atomics), and ONE slab kernel serves every slab: an LDS open-addressing table (CAS insert, atomicMin first
+//     index, count), the cells' points bucketed contiguously by a scan over the table -> O(points) LDS work instead of
+//     the O(n_s^2) compare loop (a per-cell linked list was tried first: dependent LDS reads, 40 us on the pillar grid).
 //   * balanced slabs need no histogram pass: every slab owns a fixed 2048-entry region (mean fill <= 1024) that is
 //     filled in ONE binning pass; the rare entries that do not fit go to a shared overflow list and their slab is ranked
 //     on global arrays (it would not fit LDS anyway).
@@ -25,7 +26,10 @@
 //     order means), so a wave stages its first points in LDS and streams rows*T*16 contiguous bytes with full 1 KB
 //     wave stores (zero padding included); only non-first points (multi-point cells) issue scattered 16-byte stores.
 //     coords / num_points leave as dense stores, cell coordinates are recomputed from the point (no key decode).
-//   4 kernels + 1 memset (k_bin, k_slab, k_words, k_place).  Unsupported shapes (C != 4, T > 127, key space >= 2^31, n > 8 M, > 1024 scenes, `break` cap) -> LVQ_EUNSUPPORTED
+//   4 kernels + 1 memset (k_bin, k_slab, k_words, k_place): 54 us for 8 x 65 536 points (k_place 22 us = the 93 MB output
+//   stream at ~4.5 TB/s; every stream operation costs ~4.5 us of dependent-launch latency on top of its work, which is
+//   why the count of operations was the first thing to cut).
+//   Unsupported shapes (C != 4, T > 127, key space >= 2^31, n > 8 M, > 1024 scenes, `break` cap) -> LVQ_EUNSUPPORTED
 //   and the caller falls back to voxel_binned.hip / the hash kernels in voxel.hip.
 #include "common.h"
 
@@ -38,8 +42,8 @@ struct Geom {
 };
 
 constexpr int MAX_SLABS = 8192;
-constexpr int BIN_NT = 1024;          // threads of the histogram / scatter blocks
-constexpr int BIN_PPT = 4;            // points per thread
+constexpr int BIN_NT = 1024;          // threads of a binning block
+constexpr int BIN_PPT = 4;            // points per thread (1, 2 and 4 time the same: the pass is latency-, not issue-bound)
 constexpr int SLAB_NT = 512;          // threads of a slab workgroup
 constexpr int SLAB_CAP = 2048;        // points of a slab ranked in LDS (larger slabs: same code on global arrays)
 constexpr int SLAB_TS = 2 * SLAB_CAP; // table slots in LDS
@@ -47,10 +51,8 @@ constexpr int SLAB_TS = 2 * SLAB_CAP; // table slots in LDS
 struct Ws {
     int32_t *cursor;                  // [MAX_SLABS] points per slab, then ovf_count, galloc: one memset
     int32_t *ovf_count, *galloc;
-    int32_t *sidx;                    // [nslabs * SLAB_CAP] original index, slab s owns [s * SLAB_CAP, (s+1) * SLAB_CAP)
-    uint32_t *smix;                   // same layout: mixed key (equal mix <=> equal cell)
-    int32_t *ovf_idx;                 // [n] entries that did not fit their slab's region
-    uint32_t *ovf_mix;
+    int2 *sent;                       // [nslabs * SLAB_CAP] (original index, mixed key): slab s owns [s * SLAB_CAP, (s+1) * SLAB_CAP)
+    int2 *ovf;                        // [n] entries that did not fit their slab's region
     uint8_t *fb;                      // [n+64] by ORIGINAL index: min(count, T) for the first point of a cell, else 0
     int2 *rec;                        // [n]    by ORIGINAL index, non-first points: (first index of the cell, slot)
     uint64_t *fmask;                  // [nwords+1] first-point flags, 64 points per word
@@ -76,10 +78,8 @@ template <typename A> void layout(A &a, Ws &w, int64_t n, int n_scenes) {
     w.cursor = a.template take<int32_t>(MAX_SLABS + 64);
     w.ovf_count = w.cursor ? w.cursor + MAX_SLABS : nullptr;
     w.galloc = w.cursor ? w.cursor + MAX_SLABS + 1 : nullptr;
-    w.sidx = a.template take<int32_t>(region + 1);
-    w.smix = a.template take<uint32_t>(region + 1);
-    w.ovf_idx = a.template take<int32_t>(n + 1);
-    w.ovf_mix = a.template take<uint32_t>(n + 1);
+    w.sent = a.template take<int2>(region + 1);
+    w.ovf = a.template take<int2>(n + 1);
     w.fb = a.template take<uint8_t>(n + 64);
     w.rec = a.template take<int2>(n + 1);
     w.fmask = a.template take<uint64_t>(nwords + 1);
@@ -198,14 +198,8 @@ __global__ void __launch_bounds__(BIN_NT) k_bin(const float4 *__restrict__ pts, 
         if (mk[u]) {
             const int s = shift >= 32 ? 0 : (int)(mk[u] >> shift);
             const int pos = lb[s] + rk[u];
-            if (pos < SLAB_CAP) {
-                w.sidx[(int64_t)s * SLAB_CAP + pos] = i;
-                w.smix[(int64_t)s * SLAB_CAP + pos] = mk[u];
-            } else {
-                const int o = atomicAdd(w.ovf_count, 1);
-                w.ovf_idx[o] = i;
-                w.ovf_mix[o] = mk[u];
-            }
+            if (pos < SLAB_CAP) w.sent[(int64_t)s * SLAB_CAP + pos] = make_int2(i, (int)mk[u]);     // one 8-byte store
+            else w.ovf[atomicAdd(w.ovf_count, 1)] = make_int2(i, (int)mk[u]);
         }
     }
 }
@@ -229,7 +223,7 @@ __device__ __forceinline__ void write_rank(const Ws &w, int T, int idx, int f, i
 }
 
 // LDS form (np <= SLAB_CAP): a thread keeps its <= 4 points (index, key, table slot) in registers across the phases
-__device__ __forceinline__ void slab_rank_lds(const int32_t *__restrict__ sidx, const uint32_t *__restrict__ smix, int np, int T,
+__device__ __forceinline__ void slab_rank_lds(const int2 *__restrict__ sent, int np, int T,
                                               const Ws &w, int32_t *bucket, uint32_t *t_key, int32_t *t_cnt, int32_t *t_first,
                                               int32_t *t_start, int ts, int *wave_tot) {
     constexpr int PPT = SLAB_CAP / SLAB_NT;
@@ -240,8 +234,9 @@ __device__ __forceinline__ void slab_rank_lds(const int32_t *__restrict__ sidx, 
 #pragma unroll
     for (int u = 0; u < PPT; ++u) {
         const int j = tid + u * SLAB_NT;
-        idx[u] = j < np ? sidx[j] : 0;
-        m[u] = j < np ? smix[j] : 0u;
+        const int2 e = j < np ? sent[j] : make_int2(0, 0);
+        idx[u] = e.x;
+        m[u] = (uint32_t)e.y;
     }
     for (int x = tid; x < ts; x += SLAB_NT) { t_key[x] = 0u; t_cnt[x] = 0; t_first[x] = 0x7fffffff; }
     __syncthreads();
@@ -347,8 +342,7 @@ __global__ void __launch_bounds__(SLAB_NT) k_slab(int T, int shift, Ws w) {
     const int s = blockIdx.x, tid = threadIdx.x;
     const int np = w.cursor[s];                 // every point of the slab: region entries + its share of the overflow list
     if (np == 0) return;
-    const int32_t *sidx = w.sidx + (int64_t)s * SLAB_CAP;
-    const uint32_t *smix = w.smix + (int64_t)s * SLAB_CAP;
+    const int2 *sent = w.sent + (int64_t)s * SLAB_CAP;
     if (np <= SLAB_CAP) {
         int32_t *bucket = reinterpret_cast<int32_t *>(smem);
         uint32_t *t_key = reinterpret_cast<uint32_t *>(bucket + SLAB_CAP);
@@ -356,7 +350,7 @@ __global__ void __launch_bounds__(SLAB_NT) k_slab(int T, int shift, Ws w) {
         int32_t *t_first = t_cnt + SLAB_TS, *t_start = t_first + SLAB_TS;
         int ts = 64;
         while (ts < 2 * np) ts <<= 1;
-        slab_rank_lds(sidx, smix, np, T, w, bucket, t_key, t_cnt, t_first, t_start, ts, wave_tot);
+        slab_rank_lds(sent, np, T, w, bucket, t_key, t_cnt, t_first, t_start, ts, wave_tot);
     } else {
         // oversize: gather the slab's points (region + matching overflow entries) into a contiguous global list
         if (tid == 0) { l_goff = atomicAdd(w.galloc, np); l_fill = SLAB_CAP; }
@@ -364,13 +358,14 @@ __global__ void __launch_bounds__(SLAB_NT) k_slab(int T, int shift, Ws w) {
         const int64_t goff = l_goff;
         int32_t *gi = w.g_idx + goff;
         uint32_t *gm = w.g_mix + goff;
-        for (int j = tid; j < SLAB_CAP; j += SLAB_NT) { gi[j] = sidx[j]; gm[j] = smix[j]; }
+        for (int j = tid; j < SLAB_CAP; j += SLAB_NT) { const int2 e = sent[j]; gi[j] = e.x; gm[j] = (uint32_t)e.y; }
         const int novf = *w.ovf_count;
         for (int o = tid; o < novf; o += SLAB_NT) {
-            const uint32_t m = w.ovf_mix[o];
+            const int2 e = w.ovf[o];
+            const uint32_t m = (uint32_t)e.y;
             if ((shift >= 32 ? 0 : (int)(m >> shift)) == s) {
                 const int q = atomicAdd(&l_fill, 1);
-                gi[q] = w.ovf_idx[o];
+                gi[q] = e.x;
                 gm[q] = m;
             }
         }
