@@ -138,13 +138,53 @@ __global__ void __launch_bounds__(1024) k_scan_small(const int32_t *__restrict__
 }
 
 // ---- pass A3: scatter (orig idx, in-slab offset[, point]) grouped by slab ----
+// scan_here != 0 (dynamic path): the block scans the global histogram itself (<= 8192 entries, L2-resident) instead of a
+// separate single-workgroup scan kernel; block 0 publishes gstart[0..nslabs] and the number of valid points.
 __global__ void __launch_bounds__(BIN_BLOCK) k_bin_scatter(const float *__restrict__ pts, int n, int c, Geom g, BinCfg cfg,
                                                            const int32_t *__restrict__ scene_off,
-                                                           const int32_t *__restrict__ gstart, int32_t *__restrict__ cursor,
+                                                           int32_t *__restrict__ gstart, int32_t *__restrict__ cursor,
                                                            int32_t *__restrict__ sidx, int32_t *__restrict__ soff,
-                                                           float4 *__restrict__ spts) {
+                                                           float4 *__restrict__ spts, const int32_t *__restrict__ ghist_or_null,
+                                                           int32_t *__restrict__ total_out) {
     extern __shared__ int32_t lds[];
-    int32_t *lh = lds, *lb = lds + cfg.nslabs;
+    __shared__ int wave_tot_s[BIN_BLOCK / 64];
+    int32_t *lh = lds, *lb = lds + cfg.nslabs, *gs = lds + 2 * cfg.nslabs;
+    if (ghist_or_null) {
+        const int per = (cfg.nslabs + BIN_BLOCK - 1) / BIN_BLOCK;
+        int csum = 0;
+        for (int j = 0; j < per; ++j) {
+            const int b = threadIdx.x * per + j;
+            if (b < cfg.nslabs) csum += ghist_or_null[b];
+        }
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        int incl = csum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_tot_s[wid] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+        for (int w = 0; w < BIN_BLOCK / 64; ++w) {
+            const int t = wave_tot_s[w];
+            if (w < wid) wbase += t;
+            tot += t;
+        }
+        int ex = wbase + incl - csum;
+        for (int j = 0; j < per; ++j) {
+            const int b = threadIdx.x * per + j;
+            if (b < cfg.nslabs) {
+                gs[b] = ex;
+                if (blockIdx.x == 0) gstart[b] = ex;
+                ex += ghist_or_null[b];
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            gstart[cfg.nslabs] = tot;
+            if (total_out) *total_out = tot;
+        }
+    }
     for (int b = threadIdx.x; b < cfg.nslabs; b += BIN_BLOCK) lh[b] = 0;
     __syncthreads();
     const int base = blockIdx.x * (BIN_BLOCK * BIN_PPT);
@@ -162,7 +202,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) k_bin_scatter(const float *__restri
     __syncthreads();
     for (int b = threadIdx.x; b < cfg.nslabs; b += BIN_BLOCK) {
         const int h = lh[b];
-        lb[b] = h ? gstart[b] + atomicAdd(&cursor[b], h) : 0;
+        lb[b] = h ? (ghist_or_null ? gs[b] : gstart[b]) + atomicAdd(&cursor[b], h) : 0;
         lh[b] = 0;
     }
     __syncthreads();
@@ -248,20 +288,39 @@ constexpr int DYN_VCAP = 4096;   // per-slab voxel counters held in LDS
 // ---- dynamic pass B': ranks, inverse map, sequential unique outputs ----
 __global__ void __launch_bounds__(SLAB_NT) k_dyn_slab_write(BinCfg cfg, Geom g, const int32_t *__restrict__ gstart,
                                                         const int32_t *__restrict__ sidx, const int32_t *__restrict__ soff,
-                                                        const int32_t *__restrict__ slab_vbase, int32_t *__restrict__ unq_inv,
+                                                        const int32_t *__restrict__ slab_cnt, int32_t *__restrict__ unq_inv,
                                                         int32_t *__restrict__ unq_key, int32_t *__restrict__ unq_cnt,
-                                                        int32_t *__restrict__ coords_bzyx) {
+                                                        int32_t *__restrict__ coords_bzyx, int32_t *__restrict__ m_out) {
     extern __shared__ unsigned long long smem64[];
     __shared__ int wave_tot[SLAB_NT / 64];
     const int s = blockIdx.x;
     const int p0 = gstart[s], p1 = gstart[s + 1];
-    if (p0 == p1) return;
+    if (p0 == p1 && s != 0) return;
+    // first voxel of this slab = occupied cells of all slabs before it: every block sums the <= 8192 per-slab counts itself
+    // (no single-workgroup scan kernel in between); block 0 also publishes the total M
+    int before = 0, all = 0;
+    for (int b = threadIdx.x; b < cfg.nslabs; b += SLAB_NT) {
+        const int v = slab_cnt[b];
+        all += v;
+        if (b < s) before += v;
+    }
+    int vbase, total;
+    block_excl_scan256(before, wave_tot, vbase);
+    if (s == 0) {
+        block_excl_scan256(all, wave_tot, total);
+        if (threadIdx.x == 0) *m_out = total;
+        if (p0 == p1) return;
+    }
+    const int nvox = slab_cnt[s];
     const int nw = 1 << (cfg.logslab - 6);
     unsigned long long *bm = smem64;                               // [nw]
     int32_t *wpre = reinterpret_cast<int32_t *>(smem64 + nw);      // [nw]
     int32_t *cnt_l = wpre + nw;                                    // [DYN_VCAP]
-    const int vbase = slab_vbase[s], nvox = slab_vbase[s + 1] - vbase;
     const bool lds_cnt = nvox <= DYN_VCAP;
+    if (!lds_cnt) {                                   // oversized slab: counters live in this slab's range of unq_cnt
+        for (int v = threadIdx.x; v < nvox; v += SLAB_NT) unq_cnt[vbase + v] = 0;
+        __threadfence();
+    }
     for (int w = threadIdx.x; w < nw; w += SLAB_NT) bm[w] = 0ull;
     for (int v = threadIdx.x; v < DYN_VCAP; v += SLAB_NT) cnt_l[v] = 0;
     __syncthreads();
@@ -319,13 +378,6 @@ __global__ void __launch_bounds__(SLAB_NT) k_dyn_slab_write(BinCfg cfg, Geom g, 
     }
 }
 
-// oversized slabs use global counters: zero the count array first (only when some slab may exceed the LDS cap)
-__global__ void k_zero_i32(int32_t *p, int64_t n) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) p[i] = 0;
-}
-
 // slab size: average ~256-512 points per slab, dense bitmap <= 16 KB (logslab <= 17), at most MAX_SLABS slabs
 static bool choose_cfg(int64_t keyspace, int64_t n, BinCfg &cfg) {
     if (keyspace <= 0 || keyspace > (1ll << 30)) return false;
@@ -347,9 +399,9 @@ struct DynBinWs {
 };
 
 template <typename A> void dyn_layout(A &a, DynBinWs &w, int64_t n) {
-    w.ghist = a.template take<int32_t>(MAX_SLABS + 1);
+    w.ghist = a.template take<int32_t>(2 * (MAX_SLABS + 64));
+    w.cursor = w.ghist ? w.ghist + MAX_SLABS + 64 : nullptr;
     w.gstart = a.template take<int32_t>(MAX_SLABS + 2);
-    w.cursor = a.template take<int32_t>(MAX_SLABS + 1);
     w.slab_cnt = a.template take<int32_t>(MAX_SLABS + 1);
     w.slab_vbase = a.template take<int32_t>(MAX_SLABS + 2);
     w.sidx = a.template take<int32_t>(n + 1);
@@ -636,22 +688,18 @@ int lvq_binned_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_si
     for (int j = 0; j < 3; ++j) { g.lo[j] = range_host[j]; g.vs[j] = vsize_host[j]; g.grid[j] = grid_host[j]; }
     const unsigned nb = (unsigned)lvq_cdiv(n, BIN_BLOCK * BIN_PPT);
     const int64_t cap = n < keyspace ? n : keyspace;
-    hipMemsetAsync(w.ghist, 0, sizeof(int32_t) * (cfg.nslabs + 1), st);
-    // a slab can only exceed the LDS counter cap if it can hold that many cells AND there are that many points
-    const bool may_overflow = (1 << cfg.logslab) > DYN_VCAP && n > DYN_VCAP;
-    if (may_overflow) hipLaunchKernelGGL(k_zero_i32, dim3((unsigned)(lvq_cdiv(cap, 256) < 1024 ? lvq_cdiv(cap, 256) : 1024)), dim3(256), 0, st, unq_cnt, cap);
+    hipMemsetAsync(w.ghist, 0, sizeof(int32_t) * 2 * (MAX_SLABS + 64), st);      // histogram + cursors (contiguous)
     hipLaunchKernelGGL(k_bin_hist, dim3(nb), dim3(BIN_BLOCK), sizeof(int32_t) * cfg.nslabs, st, pts, (int)n, c, g, cfg,
                        (const int32_t *)nullptr, w.ghist, pt_coords, unq_inv);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, w.ghist, cfg.nslabs, w.gstart, w.cursor, &counts[1]);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(BIN_BLOCK), 2 * sizeof(int32_t) * cfg.nslabs, st, pts, (int)n, c, g, cfg,
-                       (const int32_t *)nullptr, w.gstart, w.cursor, w.sidx, w.soff, (float4 *)nullptr);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(BIN_BLOCK), 3 * sizeof(int32_t) * cfg.nslabs, st, pts, (int)n, c, g, cfg,
+                       (const int32_t *)nullptr, w.gstart, w.cursor, w.sidx, w.soff, (float4 *)nullptr, (const int32_t *)w.ghist,
+                       &counts[1]);
     const int nw = 1 << (cfg.logslab - 6);
     hipLaunchKernelGGL(k_dyn_slab_count, dim3(cfg.nslabs), dim3(SLAB_NT), sizeof(unsigned long long) * nw, st, cfg, w.gstart, w.soff,
                        w.slab_cnt);
-    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, w.slab_cnt, cfg.nslabs, w.slab_vbase, (int32_t *)nullptr, &counts[0]);
     const size_t lds = sizeof(unsigned long long) * nw + sizeof(int32_t) * nw + sizeof(int32_t) * DYN_VCAP;
-    hipLaunchKernelGGL(k_dyn_slab_write, dim3(cfg.nslabs), dim3(SLAB_NT), lds, st, cfg, g, w.gstart, w.sidx, w.soff, w.slab_vbase, unq_inv,
-                       unq_key, unq_cnt, coords_bzyx);
+    hipLaunchKernelGGL(k_dyn_slab_write, dim3(cfg.nslabs), dim3(SLAB_NT), lds, st, cfg, g, w.gstart, w.sidx, w.soff, w.slab_cnt, unq_inv,
+                       unq_key, unq_cnt, coords_bzyx, &counts[0]);
     return lvq_launch_status();
 }
 
@@ -686,8 +734,8 @@ int lvq_binned_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t
     hipLaunchKernelGGL(k_bin_hist, dim3(nb), dim3(BIN_BLOCK), sizeof(int32_t) * cfg.nslabs, st, pts, (int)n, c, g, cfg, scene_off, w.ghist,
                        (int32_t *)nullptr, (int32_t *)nullptr);
     hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, st, w.ghist, cfg.nslabs, w.gstart, w.cursor, (int32_t *)nullptr);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(BIN_BLOCK), 2 * sizeof(int32_t) * cfg.nslabs, st, pts, (int)n, c, g, cfg, scene_off,
-                       w.gstart, w.cursor, w.sidx, w.soff, w.spts);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nb), dim3(BIN_BLOCK), 3 * sizeof(int32_t) * cfg.nslabs, st, pts, (int)n, c, g, cfg, scene_off,
+                       w.gstart, w.cursor, w.sidx, w.soff, w.spts, (const int32_t *)nullptr, (int32_t *)nullptr);
     const int nw = 1 << (cfg.logslab - 6);
     const size_t lds = sizeof(unsigned long long) * nw + sizeof(int32_t) * nw + sizeof(int32_t) * (4 * HARD_VCAP + HARD_PCAP);
     static bool attr = false;
