@@ -241,6 +241,35 @@ int lvq_swiglu(const float *gate_up, int64_t rows, int inter, lvq_bf16 *out_hi, 
 int lvq_cross_entropy(const float *logits, const int64_t *labels, int64_t rows, int vocab, float *loss_sum_cnt,
                       lvq_stream_t stream);
 
+/* =====================================================================================
+ * Data formats either side of the sparse backbone
+ * ===================================================================================== */
+
+/* f2  encoder-decoder/training/data/dataset.py:139-146: `torch.from_numpy(np.load(path)).float()` of the stored fp16 BEV
+ * [C,H,W] (writer: get-data/precompute_bev_features.py:391-395).  dst[i] = (float)src[i], exact.  src/dst 16-byte aligned. */
+int lvq_f16_to_f32(const uint16_t *src, float *dst, int64_t n, lvq_stream_t stream);
+
+/* f3  pcdet/models/backbones_3d/spconv_backbone_voxelnext.py:149-164  VoxelResBackBone8xVoxelNeXt.bev_out:
+ *   indices_cat = indices[:, [0, 2, 3]];  indices_unique, inv = torch.unique(indices_cat, dim=0, return_inverse=True)
+ *   features_unique = zeros(len(indices_unique), C).index_add_(0, inv, features)
+ * indices_bzyx [m,4] int32 (b, z, y, x), feats [m,c] fp32, grid (ny, nx) = spatial_shape[1:].
+ *   out_indices_byx [cap,3] int32: unique (b, y, x) rows in ascending lexicographic order (= torch.unique(dim=0))
+ *   out_feats [cap,c] fp32: MUST BE ZERO ON ENTRY; sums (fp32 atomics, order unspecified as in the CUDA index_add_)
+ *   unq_inv [m] int32: row of out_* each input row was added to;  counts [2] int32: counts[0] = number of unique rows
+ *   cap >= min(m, batch*ny*nx).  batch*ny*nx must stay below 2^31 (LVQ_EOVERFLOW). */
+size_t lvq_sparse_bev_merge_workspace_bytes(int64_t m, int batch, int ny, int nx);
+int lvq_sparse_bev_merge(const int32_t *indices_bzyx, const float *feats, int64_t m, int c, int batch, int ny, int nx,
+                         int32_t *out_indices_byx, float *out_feats, int32_t *unq_inv, int32_t *counts, void *ws,
+                         size_t ws_bytes, lvq_stream_t stream);
+
+/* f3  pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-26  HeightCompression.forward:
+ * SparseConvTensor.dense() -> [N, C, D, H, W] -> view(N, C*D, H, W), i.e. out[b, ch*d + z, y, x] = feats[r, ch].
+ * indices [m_cap, index_cols] int32: index_cols == 4 -> (b, z, y, x); index_cols == 3 -> (b, y, x) with d == 1 (the
+ * `.dense()` of the 2-D tensor bev_out returns, stored by precompute_bev_features.py).  out is zero-filled here;
+ * rows >= *n_live_dev are skipped (NULL = all m_cap rows). */
+int lvq_sparse_to_dense(const float *feats, const int32_t *indices, int index_cols, int64_t m_cap, const int32_t *n_live_dev,
+                        int c, int batch, int d, int h, int w, float *out, lvq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,190 @@
+// csrc/bev_bridge.hip -- the data formats either side of the sparse backbone, gfx950.
+//
+//   lvq_f16_to_f32          f2  training/data/dataset.py:139-146: `torch.from_numpy(np.load(path)).float()` -- the stored
+//                               fp16 BEV [C,H,W] (writer: get-data/precompute_bev_features.py:391-395) up-cast on load.
+//                               Exact (every fp16 value is an fp32 value); HBM-bound, 6 bytes per element.
+//   lvq_sparse_bev_merge    f3  spconv_backbone_voxelnext.py:149-164 `bev_out`: indices[:, [0,2,3]] -> torch.unique(dim=0,
+//                               return_inverse) (rows sorted lexicographically by (b, y, x)) -> index_add_ of the features.
+//                               The unique step IS the dynamic voxeliser's problem (integer cells instead of points), so it
+//                               runs on the same slab-binned kernels: key = (b*ny + y)*nx + x ascending == the row order of
+//                               torch.unique(dim=0).  index_add_ = one fp32 atomic per (row, channel), coalesced over channels
+//                               (the reference's CUDA index_add_ is atomic too: summation order is unspecified there as well).
+//   lvq_sparse_to_dense     f3  map_to_bev/height_compression.py:10-26: SparseConvTensor.dense() [N,C,D,H,W] viewed as
+//                               [N, C*D, H, W]; with D == 1 and (b, y, x) indices it is the `.dense()` that
+//                               precompute_bev_features.py stores.  Zero-fill + scatter.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+namespace {
+
+__device__ __forceinline__ float h2f(unsigned short u) {
+    __half_raw r;
+    r.x = u;
+    return __half2float(__half(r));
+}
+
+__global__ void __launch_bounds__(256) k_f16_to_f32(const uint16_t *__restrict__ src, float *__restrict__ dst, int64_t n) {
+    // 8 halves (16 bytes) in, 32 bytes out per thread
+    const int64_t i8 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i8 + 8 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + i8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[2 * k] = h2f((unsigned short)(w[k] & 0xffffu));
+            o[2 * k + 1] = h2f((unsigned short)(w[k] >> 16));
+        }
+        float4 *d4 = reinterpret_cast<float4 *>(dst + i8);
+        d4[0] = make_float4(o[0], o[1], o[2], o[3]);
+        d4[1] = make_float4(o[4], o[5], o[6], o[7]);
+    } else {
+        for (int64_t i = i8; i < n; ++i) dst[i] = h2f(src[i]);
+    }
+}
+
+// (b, z, y, x) int32 rows -> the "points" the dynamic voxeliser takes: (batch, x' = y, y' = x, 0) with unit cells
+__global__ void __launch_bounds__(256) k_idx_to_pts(const int4 *__restrict__ idx, int64_t m, float4 *__restrict__ pts) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const int4 v = idx[i];
+    pts[i] = make_float4((float)v.x, (float)v.z, (float)v.w, 0.0f);
+}
+
+// dynamic voxeliser cells (b, 0, cy' = x, cx' = y) -> unique index rows (b, y, x)
+__global__ void __launch_bounds__(256) k_cells_to_byx(const int4 *__restrict__ cells, const int32_t *__restrict__ counts, int64_t cap,
+                                                      int32_t *__restrict__ out_byx) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    int64_t m = counts[0];
+    if (m > cap) m = cap;
+    if (v >= m) return;
+    const int4 c = cells[v];
+    out_byx[v * 3] = c.x;
+    out_byx[v * 3 + 1] = c.w;
+    out_byx[v * 3 + 2] = c.z;
+}
+
+// features_unique.index_add_(0, inv, features): lanes run over channels (coalesced reads, atomics of one row share lines)
+__global__ void __launch_bounds__(256) k_index_add(const float *__restrict__ feats, int64_t m, int c, const int32_t *__restrict__ inv,
+                                                   float *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m * c) return;
+    const int64_t r = e / c;
+    const int k = (int)(e - r * c);
+    const int v = inv[r];
+    if (v < 0) return;                       // row outside the grid (the reference never produces one)
+    atomicAdd(&out[(int64_t)v * c + k], feats[e]);
+}
+
+__global__ void __launch_bounds__(256) k_fill_zero(float4 *__restrict__ p, int64_t n4) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n4; i += stride) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// out[b, ch*d + z, y, x] = feats[r, ch]; one thread per row, rows of neighbouring cells share output lines per channel
+__global__ void __launch_bounds__(256) k_sparse_to_dense(const float *__restrict__ feats, const int32_t *__restrict__ idx, int icols,
+                                                         int64_t m_cap, const int32_t *__restrict__ n_live, int c, int batch, int d, int h,
+                                                         int w, float *__restrict__ out) {
+    int64_t m = n_live ? (int64_t)*n_live : m_cap;
+    if (m > m_cap) m = m_cap;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    const int32_t *row = idx + r * icols;
+    const int b = row[0];
+    const int z = icols == 4 ? row[1] : 0, y = row[icols - 2], x = row[icols - 1];
+    if (b < 0 || b >= batch || z < 0 || z >= d || y < 0 || y >= h || x < 0 || x >= w) return;
+    const int64_t plane = (int64_t)h * w;
+    float *dst = out + ((int64_t)b * c * d + z) * plane + (int64_t)y * w + x;
+    const float *src = feats + r * c;
+    for (int k = 0; k < c; ++k) dst[(int64_t)k * d * plane] = src[k];
+}
+
+}  // namespace
+
+extern "C" int lvq_f16_to_f32(const uint16_t *src, float *dst, int64_t n, lvq_stream_t stream) {
+    if (n < 0) return LVQ_EINVAL;
+    if (n == 0) return LVQ_OK;
+    if (!src || !dst) return LVQ_EINVAL;
+    if ((((uintptr_t)src) & 15) || (((uintptr_t)dst) & 15)) return LVQ_EUNSUPPORTED;
+    hipLaunchKernelGGL(k_f16_to_f32, dim3((unsigned)lvq_cdiv(lvq_cdiv(n, 8), 256)), dim3(256), 0, lvq_s(stream), src, dst, n);
+    return lvq_launch_status();
+}
+
+namespace {
+struct MergeWs {
+    float4 *pts;
+    int32_t *unq_key, *unq_cnt, *cells;
+    void *dyn;
+    size_t dyn_bytes;
+};
+template <typename A> void merge_layout(A &a, MergeWs &w, int64_t m, size_t dyn_bytes) {
+    w.pts = a.template take<float4>(m + 1);
+    w.unq_key = a.template take<int32_t>(m + 1);
+    w.unq_cnt = a.template take<int32_t>(m + 1);
+    w.cells = a.template take<int32_t>(4 * (m + 1));
+    w.dyn = a.template take<char>(dyn_bytes);
+    w.dyn_bytes = dyn_bytes;
+}
+struct SizerA {
+    LvqSizer s;
+    template <typename T> T *take(size_t n) { s.template take<T>(n); return nullptr; }
+};
+}  // namespace
+
+extern "C" size_t lvq_sparse_bev_merge_workspace_bytes(int64_t m, int batch, int ny, int nx) {
+    if (m < 0 || batch <= 0 || ny <= 0 || nx <= 0) return 0;
+    const int32_t grid[3] = {ny, nx, 1};
+    const size_t dyn = lvq_voxelize_dynamic_workspace_bytes(m, batch, grid, 2);
+    if (dyn == 0) return 0;
+    SizerA a;
+    MergeWs w;
+    merge_layout(a, w, m, dyn);
+    return a.s.total();
+}
+
+extern "C" int lvq_sparse_bev_merge(const int32_t *indices_bzyx, const float *feats, int64_t m, int c, int batch, int ny, int nx,
+                                    int32_t *out_indices_byx, float *out_feats, int32_t *unq_inv, int32_t *counts, void *ws,
+                                    size_t ws_bytes, lvq_stream_t stream) {
+    if (m < 0 || c <= 0 || batch <= 0 || ny <= 0 || nx <= 0 || !counts) return LVQ_EINVAL;
+    if (ny >= (1 << 24) || nx >= (1 << 24) || batch >= (1 << 24)) return LVQ_EUNSUPPORTED;     // indices pass through fp32 exactly
+    hipStream_t st = lvq_s(stream);
+    if (m == 0) {
+        hipMemsetAsync(counts, 0, 2 * sizeof(int32_t), st);
+        return lvq_launch_status();
+    }
+    if (!indices_bzyx || !feats || !out_indices_byx || !out_feats || !unq_inv || (((uintptr_t)indices_bzyx) & 15)) return LVQ_EINVAL;
+    const int32_t grid[3] = {ny, nx, 1};
+    const size_t dyn = lvq_voxelize_dynamic_workspace_bytes(m, batch, grid, 2);
+    if (dyn == 0) return LVQ_EOVERFLOW;
+    LvqArena arena(ws, ws_bytes);
+    MergeWs w;
+    merge_layout(arena, w, m, dyn);
+    if (!arena.ok) return LVQ_EWORKSPACE;
+    const unsigned nb = (unsigned)lvq_cdiv(m, 256);
+    hipLaunchKernelGGL(k_idx_to_pts, dim3(nb), dim3(256), 0, st, reinterpret_cast<const int4 *>(indices_bzyx), m, w.pts);
+    const float range[6] = {0.f, 0.f, 0.f, (float)ny, (float)nx, 1.f};
+    const float vsize[3] = {1.f, 1.f, 1.f};
+    const int rc = lvq_voxelize_dynamic(reinterpret_cast<const float *>(w.pts), m, 4, batch, range, vsize, grid, 2, unq_inv, nullptr,
+                                        w.unq_key, w.unq_cnt, w.cells, counts, w.dyn, w.dyn_bytes, stream);
+    if (rc != LVQ_OK) return rc;
+    hipLaunchKernelGGL(k_cells_to_byx, dim3(nb), dim3(256), 0, st, reinterpret_cast<const int4 *>(w.cells), counts, m, out_indices_byx);
+    hipLaunchKernelGGL(k_index_add, dim3((unsigned)lvq_cdiv(m * c, 256)), dim3(256), 0, st, feats, m, c, unq_inv, out_feats);
+    return lvq_launch_status();
+}
+
+extern "C" int lvq_sparse_to_dense(const float *feats, const int32_t *indices, int index_cols, int64_t m_cap, const int32_t *n_live_dev,
+                                   int c, int batch, int d, int h, int w, float *out, lvq_stream_t stream) {
+    if (m_cap < 0 || c <= 0 || batch <= 0 || d <= 0 || h <= 0 || w <= 0 || !out || (index_cols != 3 && index_cols != 4)) return LVQ_EINVAL;
+    if (index_cols == 3 && d != 1) return LVQ_EINVAL;
+    hipStream_t st = lvq_s(stream);
+    const int64_t total = (int64_t)batch * c * d * h * w;
+    if ((((uintptr_t)out) & 15) || (total & 3)) hipMemsetAsync(out, 0, (size_t)total * sizeof(float), st);
+    else hipLaunchKernelGGL(k_fill_zero, dim3((unsigned)(lvq_cdiv(total / 4, 256) < 65536 ? lvq_cdiv(total / 4, 256) : 65536)), dim3(256), 0, st,
+                            reinterpret_cast<float4 *>(out), total / 4);
+    if (m_cap == 0) return lvq_launch_status();
+    if (!feats || !indices) return LVQ_EINVAL;
+    hipLaunchKernelGGL(k_sparse_to_dense, dim3((unsigned)lvq_cdiv(m_cap, 256)), dim3(256), 0, st, feats, indices, index_cols, m_cap, n_live_dev,
+                       c, batch, d, h, w, out);
+    return lvq_launch_status();
+}

@@ -1,0 +1,97 @@
+"""GPU parity tests of the data-format rows through the C ABI: fp16 BEV loader (bit-exact), sparse
+z-merge (`bev_out`: indices / inverse bit-exact, fp32 sums within atomics' reordering), HeightCompression (bit-exact)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bev_oracle as BO
+from test_bev_bridge import synth_sparse
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def B():
+    from lidar_vision_vqa_amd import bev
+    return bev
+
+
+class Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 4099, 128 * 180 * 180])
+def test_f16_to_f32_exact(n):
+    rng = np.random.default_rng(n)
+    h = rng.standard_normal(n).astype(np.float16)
+    if n >= 7:
+        h[:7] = np.array([np.inf, -np.inf, 0.0, -0.0, 6.1e-5, 5.96e-8, 65504.0], np.float16)    # inf, zeros, subnormals, max
+    got = B().f16_to_f32(torch.from_numpy(h).to(DEV)).cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), h.astype(np.float32).view(np.uint32))
+    if n >= 8:
+        hn = h.copy()
+        hn[7] = np.float16(np.nan)
+        gn = B().f16_to_f32(torch.from_numpy(hn).to(DEV)).cpu().numpy()
+        assert np.isnan(gn[7]) and np.array_equal(np.isnan(gn), np.isnan(hn))
+
+
+def test_bev_feature_store_reference_shape(tmp_path):
+    """Three [128,180,180] fp16 files (the shape precompute_bev_features.py writes) in nested split directories."""
+    bev = B()
+    rng = np.random.default_rng(7)
+    (tmp_path / "train").mkdir()
+    (tmp_path / "val").mkdir()
+    toks = ["a1", "b2", "c3"]
+    for k, t in enumerate(toks):
+        bev.save_bev_feature(tmp_path / ("train" if k < 2 else "val") / f"{t}.npy", rng.standard_normal((128, 180, 180)).astype(np.float32) * 3)
+    store = bev.BevFeatureStore([str(tmp_path)], DEV)
+    assert len(store) == 3 and "b2" in store and "zz" not in store
+    for order in (["c3", "a1"], ["a1", "b2", "c3"], ["b2"]):            # the pinned staging buffer is reused between calls
+        got = store.load(order)
+        exp = np.stack([BO.load_bev(store.token2path[t]) for t in order])
+        assert got.dtype == torch.float32 and tuple(got.shape) == exp.shape
+        assert np.array_equal(got.cpu().numpy().view(np.uint32), exp.view(np.uint32))
+    with pytest.raises(KeyError):
+        store.load(["nope"])
+
+
+@pytest.mark.parametrize("seed,batch,d,h,w,m,c", [(1, 2, 5, 18, 18, 400, 16), (2, 1, 2, 7, 9, 60, 3), (3, 3, 5, 45, 45, 5000, 128),
+                                                  (4, 4, 5, 180, 180, 120000, 128)])       # last: the reference's true BEV grid
+def test_bev_out_vs_oracle(seed, batch, d, h, w, m, c):
+    bev = B()
+    feats, idx = synth_sparse(seed, batch, d, h, w, m, c)
+    of, oi, oinv = BO.bev_out(feats, idx)
+    x = bev.SparseTensor(torch.from_numpy(feats).to(DEV), torch.from_numpy(idx).to(DEV), (d, h, w), batch)
+    out = bev.bev_out(x)
+    assert out.spatial_shape == [h, w] and out.batch_size == batch
+    assert np.array_equal(out.indices.cpu().numpy(), oi)                 # unique rows + their order: bit-exact
+    got = out.features.cpu().numpy()
+    assert got.shape == of.shape
+    assert np.allclose(got, of, rtol=1e-5, atol=1e-5)                    # fp32 sums of <= d terms, atomics reorder them
+    # the dense BEV the VQA pipeline stores (precompute_bev_features.py: encoded tensor -> .dense()) and HeightCompression
+    dn = out.dense().cpu().numpy()
+    assert np.allclose(dn, BO.dense(of, oi, (h, w), batch), rtol=1e-5, atol=1e-5)
+    exact = bev.SparseTensor(torch.from_numpy(of).to(DEV), torch.from_numpy(oi).to(DEV), (h, w), batch).dense().cpu().numpy()
+    assert np.array_equal(exact, BO.dense(of, oi, (h, w), batch))        # the scatter itself: bit-exact
+
+
+def test_bev_out_empty_and_single():
+    bev = B()
+    x = bev.SparseTensor(torch.zeros((0, 8), device=DEV), torch.zeros((0, 4), dtype=torch.int32, device=DEV), (5, 10, 10), 2)
+    out = bev.bev_out(x)
+    assert tuple(out.features.shape) == (0, 8) and tuple(out.indices.shape) == (0, 3)
+    assert float(out.dense().abs().sum()) == 0.0
+    x = bev.SparseTensor(torch.ones((3, 2), device=DEV), torch.tensor([[1, 0, 4, 4], [1, 3, 4, 4], [0, 1, 9, 0]], dtype=torch.int32, device=DEV),
+                         (5, 10, 10), 2)
+    out = bev.bev_out(x)
+    assert out.indices.cpu().tolist() == [[0, 9, 0], [1, 4, 4]] and out.features.cpu().tolist() == [[1.0, 1.0], [2.0, 2.0]]
+
+
+def test_height_compression_module_3d():
+    bev = B()
+    feats, idx = synth_sparse(9, 2, 2, 180, 180, 30000, 64)
+    x = bev.SparseTensor(torch.from_numpy(feats).to(DEV), torch.from_numpy(idx).to(DEV), (2, 180, 180), 2)
+    mod = bev.HeightCompression(Cfg(NUM_BEV_FEATURES=128))
+    bd = mod({"encoded_spconv_tensor": x, "encoded_spconv_tensor_stride": 8})
+    assert bd["spatial_features_stride"] == 8 and tuple(bd["spatial_features"].shape) == (2, 128, 180, 180)
+    assert np.array_equal(bd["spatial_features"].cpu().numpy(), BO.height_compression(feats, idx, (2, 180, 180), 2))
