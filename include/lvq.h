@@ -75,6 +75,17 @@ int lvq_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n_poin
                       float *voxels, int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off,
                       void *ws, size_t ws_bytes, lvq_stream_t stream);
 
+/* a3 + a5 fused ("fused voxelise -> mean", 16 N + M (4 C + 16) bytes, no padded [M,T,C] tensor):
+ * the voxelisation of lvq_voxelize_hard (`continue` cap) whose per-voxel payload is MeanVFE's row
+ * (mean_vfe.py:25-29): voxel_features[m,:] = sum of the first min(count, T) points in input order / that count --
+ * the same fp32 additions in the same order as lvq_voxelize_hard + lvq_mean_vfe, hence bit-identical to that pair.
+ * coords / num_pts / scene_voxel_off / workspace (lvq_voxelize_hard_workspace_bytes) as for lvq_voxelize_hard.
+ * c == 4, T <= 127, key space < 2^31, N <= 8 M, <= 1024 scenes; otherwise LVQ_EUNSUPPORTED (run the pair instead). */
+int lvq_voxelize_mean(const float *pts, const int32_t *scene_off, int64_t n_points, int n_scenes, int c,
+                      const float *range_host, const float *vsize_host, const int32_t *grid_host, int max_pts,
+                      int max_voxels, int64_t voxel_capacity, float *voxel_features, int32_t *coords_bzyx,
+                      int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes, lvq_stream_t stream);
+
 /* a5  backbones_3d/vfe/mean_vfe.py:25-29  MeanVFE.forward:
  * out[m,:] = sum_t voxels[m,t,:] / max(num_pts[m],1).  n_voxels_dev (optional, may be NULL) points at
  * a device int32 holding the live row count (<= m_cap), so the call needs no host sync. */
@@ -265,10 +276,12 @@ int lvq_sparse_bev_merge(const int32_t *indices_bzyx, const float *feats, int64_
 /* f3  pcdet/models/backbones_2d/map_to_bev/height_compression.py:10-26  HeightCompression.forward:
  * SparseConvTensor.dense() -> [N, C, D, H, W] -> view(N, C*D, H, W), i.e. out[b, ch*d + z, y, x] = feats[r, ch].
  * indices [m_cap, index_cols] int32: index_cols == 4 -> (b, z, y, x); index_cols == 3 -> (b, y, x) with d == 1 (the
- * `.dense()` of the 2-D tensor bev_out returns, stored by precompute_bev_features.py).  out is zero-filled here;
- * rows >= *n_live_dev are skipped (NULL = all m_cap rows). */
+ * `.dense()` of the 2-D tensor bev_out returns, stored by precompute_bev_features.py).  Every element of out is written
+ * (zeros where no row points); rows >= *n_live_dev are skipped (NULL = all m_cap rows).  ws holds an int32 row map
+ * [batch, d, h, w]. */
+size_t lvq_sparse_to_dense_workspace_bytes(int batch, int d, int h, int w);
 int lvq_sparse_to_dense(const float *feats, const int32_t *indices, int index_cols, int64_t m_cap, const int32_t *n_live_dev,
-                        int c, int batch, int d, int h, int w, float *out, lvq_stream_t stream);
+                        int c, int batch, int d, int h, int w, float *out, void *ws, size_t ws_bytes, lvq_stream_t stream);
 
 #ifdef __cplusplus
 }

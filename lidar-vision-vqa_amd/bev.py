@@ -122,9 +122,11 @@ class SparseTensor:
         d = self.spatial_shape[0] if nd == 3 else 1
         h, w = self.spatial_shape[-2], self.spatial_shape[-1]
         out = torch.empty((self.batch_size, c * d, h, w), dtype=torch.float32, device=feats.device)
-        rc = F.lib().lvq_sparse_to_dense(F.ptr(feats), F.ptr(idx), F.cint(nd + 1), F.i64(m), F.ptr(None), F.cint(c),
-                                         F.cint(self.batch_size), F.cint(d), F.cint(h), F.cint(w), F.ptr(out),
-                                         F.stream_ptr(feats.device))
+        L = F.lib()
+        ws = workspace(L.lvq_sparse_to_dense_workspace_bytes(F.cint(self.batch_size), F.cint(d), F.cint(h), F.cint(w)), feats.device, "dense")
+        rc = L.lvq_sparse_to_dense(F.ptr(feats), F.ptr(idx), F.cint(nd + 1), F.i64(m), F.ptr(None), F.cint(c),
+                                   F.cint(self.batch_size), F.cint(d), F.cint(h), F.cint(w), F.ptr(out), F.ptr(ws), F.csize(ws.numel()),
+                                   F.stream_ptr(feats.device))
         F.check(rc, "lvq_sparse_to_dense")
         return out.view(self.batch_size, c, d, h, w) if nd == 3 else out
 

@@ -44,6 +44,11 @@ int lvq_hashed_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t
                              int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes,
                              hipStream_t st);
 
+int lvq_hashed_voxelize_mean(const float *pts, const int32_t *scene_off, int64_t n, int n_scenes, int c, const float *range_host,
+                             const float *vsize_host, const int32_t *grid_host, int max_pts, int max_voxels, float *voxel_features,
+                             int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes,
+                             hipStream_t st);
+
 namespace {
 
 struct Geom {
@@ -635,6 +640,29 @@ extern "C" int lvq_voxelize_hard(const float *pts, const int32_t *scene_off, int
                            break_on_cap, w, voxels, num_pts);
     }
     return lvq_launch_status();
+}
+
+// a3 + a5 fused (SURVEY 8d "fused voxelise -> mean, no padded tensor"): hard voxelisation whose per-voxel output is
+// MeanVFE's feature row.  Only the hash-balanced-slab path implements it; other shapes return LVQ_EUNSUPPORTED and the
+// caller runs lvq_voxelize_hard + lvq_mean_vfe.
+extern "C" int lvq_voxelize_mean(const float *pts, const int32_t *scene_off, int64_t n_points, int n_scenes, int c,
+                                 const float *range_host, const float *vsize_host, const int32_t *grid_host, int max_pts,
+                                 int max_voxels, int64_t voxel_capacity, float *voxel_features, int32_t *coords_bzyx,
+                                 int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+    if (n_points < 0 || n_scenes <= 0 || c < 3 || max_pts <= 0 || max_voxels <= 0 || !range_host || !vsize_host || !grid_host ||
+        !scene_off || !scene_voxel_off)
+        return LVQ_EINVAL;
+    for (int j = 0; j < 3; ++j)
+        if (grid_host[j] <= 0 || !(vsize_host[j] > 0.f)) return LVQ_EINVAL;
+    hipStream_t st = lvq_s(stream);
+    if (n_points == 0) {
+        hipMemsetAsync(scene_voxel_off, 0, sizeof(int32_t) * (n_scenes + 1), st);
+        return lvq_launch_status();
+    }
+    const int64_t need = n_points < (int64_t)n_scenes * max_voxels ? n_points : (int64_t)n_scenes * max_voxels;
+    if (voxel_capacity < need || !pts || !voxel_features || !coords_bzyx || !num_pts) return LVQ_EINVAL;
+    return lvq_hashed_voxelize_mean(pts, scene_off, n_points, n_scenes, c, range_host, vsize_host, grid_host, max_pts, max_voxels,
+                                    voxel_features, coords_bzyx, num_pts, scene_voxel_off, ws, ws_bytes, st);
 }
 
 static int64_t dyn_keyspace(int batch_size, const int32_t *grid, int ndim) {

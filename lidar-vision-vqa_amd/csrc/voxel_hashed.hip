@@ -55,12 +55,13 @@ struct Ws {
     int2 *ovf;                        // [n] entries that did not fit their slab's region
     uint8_t *fb;                      // [n+64] by ORIGINAL index: min(count, T) for the first point of a cell, else 0
     int2 *rec;                        // [n]    by ORIGINAL index, non-first points: (first index of the cell, slot)
+    float4 *tmean;                    // [n]    voxelise->mean form: by ORIGINAL first index, mean of a multi-point cell
     uint64_t *fmask;                  // [nwords+1] first-point flags, 64 points per word
     int32_t *wloc;                    // [nwords+2] exclusive popcount prefix of a word inside its 4096-point block
     int32_t *btot;                    // [MAX_KB+2] first points per 4096-point block
     int32_t *g_idx;                   // [n]      oversize slabs: contiguous point lists + global stand-ins for the LDS arrays
     uint32_t *g_mix;
-    int32_t *g_bucket;                // [n]
+    int32_t *g_bucket, *g_sorted;     // [n]
     uint32_t *g_key;                  // [2n+64]
     int32_t *g_cnt, *g_first, *g_start;
 };
@@ -82,12 +83,14 @@ template <typename A> void layout(A &a, Ws &w, int64_t n, int n_scenes) {
     w.ovf = a.template take<int2>(n + 1);
     w.fb = a.template take<uint8_t>(n + 64);
     w.rec = a.template take<int2>(n + 1);
+    w.tmean = a.template take<float4>(n + 1);
     w.fmask = a.template take<uint64_t>(nwords + 1);
     w.wloc = a.template take<int32_t>(nwords + 2);
     w.btot = a.template take<int32_t>(4096);
     w.g_idx = a.template take<int32_t>(n + 1);
     w.g_mix = a.template take<uint32_t>(n + 1);
     w.g_bucket = a.template take<int32_t>(n + 1);
+    w.g_sorted = a.template take<int32_t>(n + 1);
     w.g_key = a.template take<uint32_t>(2 * n + 64);
     w.g_cnt = a.template take<int32_t>(2 * n + 64);
     w.g_first = a.template take<int32_t>(2 * n + 64);
@@ -207,23 +210,32 @@ __global__ void __launch_bounds__(BIN_NT) k_bin(const float4 *__restrict__ pts, 
 // ---- K2: one workgroup per slab: open-addressing table of the slab's cells -> first index / count per cell, then the
 // cell's points are bucketed contiguously (exclusive scan of the counts over the table slots) so that the slot of a
 // point = number of smaller indices in its bucket is a run of independent reads (no pointer chasing).
-__device__ __forceinline__ void write_rank(const Ws &w, int T, int idx, int f, int cnt, const int32_t *b) {
-    if (idx == f) {
-        w.fb[idx] = (uint8_t)(cnt < T ? cnt : T);
-    } else {
-        int r = 0;
-        for (int k = 0; k < cnt && r < T; k += 4) {
+// slot of point idx = number of smaller indices in its cell's bucket b[0..cnt) (stops at T: the point is dropped then)
+__device__ __forceinline__ int bucket_rank(const int32_t *b, int cnt, int idx, int T) {
+    int r = 0;
+    for (int k = 0; k < cnt && r < T; k += 4) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (k + u < cnt) r += (b[k + u] < idx);
-        }
-        w.fb[idx] = 0;
-        w.rec[idx] = make_int2(f, r);          // r >= T: the point is not stored (only "r < T" is used)
+        for (int u = 0; u < 4; ++u)
+            if (k + u < cnt) r += (b[k + u] < idx);
     }
+    return r;
+}
+
+// mean of the first min(cnt, T) points of a cell in slot order: MeanVFE.forward (mean_vfe.py:25-29) on the row the padded
+// tensor would hold -- the same fp32 additions in the same order as lvq_mean_vfe (zeros of the padding add nothing)
+__device__ __forceinline__ float4 cell_mean(const float4 *__restrict__ pts, const int32_t *sorted, int npv) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < npv; ++k) {
+        const float4 p = pts[sorted[k]];
+        s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+    }
+    const float d = (float)npv;
+    return make_float4(s.x / d, s.y / d, s.z / d, s.w / d);
 }
 
 // LDS form (np <= SLAB_CAP): a thread keeps its <= 4 points (index, key, table slot) in registers across the phases
-__device__ __forceinline__ void slab_rank_lds(const int2 *__restrict__ sent, int np, int T,
+template <bool MEAN>
+__device__ __forceinline__ void slab_rank_lds(const float4 *__restrict__ pts, const int2 *__restrict__ sent, int np, int T,
                                               const Ws &w, int32_t *bucket, uint32_t *t_key, int32_t *t_cnt, int32_t *t_first,
                                               int32_t *t_start, int ts, int *wave_tot) {
     constexpr int PPT = SLAB_CAP / SLAB_NT;
@@ -272,17 +284,41 @@ __device__ __forceinline__ void slab_rank_lds(const int2 *__restrict__ sent, int
     for (int u = 0; u < PPT; ++u)
         if (m[u] && t_cnt[h[u]] > 1) bucket[atomicAdd(&t_start[h[u]], 1)] = idx[u];    // t_start doubles as the cursor
     __syncthreads();
+    int r[PPT], cn[PPT], bs[PPT];
 #pragma unroll
-    for (int u = 0; u < PPT; ++u)
+    for (int u = 0; u < PPT; ++u) {
+        r[u] = 0; cn[u] = 0; bs[u] = 0;
         if (m[u]) {
-            const int cnt = t_cnt[h[u]];
-            write_rank(w, T, idx[u], t_first[h[u]], cnt, bucket + (t_start[h[u]] - cnt));
+            cn[u] = t_cnt[h[u]];
+            bs[u] = t_start[h[u]] - cn[u];
+            const int f = t_first[h[u]];
+            if (idx[u] == f) {
+                w.fb[idx[u]] = (uint8_t)(cn[u] < T ? cn[u] : T);
+            } else {
+                r[u] = bucket_rank(bucket + bs[u], cn[u], idx[u], T);
+                w.fb[idx[u]] = 0;
+                if (!MEAN) w.rec[idx[u]] = make_int2(f, r[u]);      // r >= T: the point is not stored (only "r < T" is used)
+            }
         }
+    }
+    if (MEAN) {
+        // the bucket becomes the cell's first min(cnt, T) indices in slot order (every slot below that is claimed by exactly
+        // one point), then the first point of every multi-point cell sums them
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PPT; ++u)
+            if (m[u] && cn[u] > 1 && r[u] < T) bucket[bs[u] + r[u]] = idx[u];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PPT; ++u)
+            if (m[u] && cn[u] > 1 && idx[u] == t_first[h[u]]) w.tmean[idx[u]] = cell_mean(pts, bucket + bs[u], cn[u] < T ? cn[u] : T);
+    }
 }
 
 // global form: the same phases on global arrays (a slab with more than SLAB_CAP points: only inputs with ~thousands of
 // points in single cells get there; bounded, slow, exact)
-__device__ __forceinline__ void slab_rank_glob(const int32_t *sidx, const uint32_t *smix, int np, int T, const Ws &w, int32_t *bucket,
+template <bool MEAN>
+__device__ __forceinline__ void slab_rank_glob(const float4 *__restrict__ pts, int32_t *sorted, const int32_t *sidx, const uint32_t *smix, int np, int T, const Ws &w, int32_t *bucket,
                                                uint32_t *t_key, int32_t *t_cnt, int32_t *t_first, int32_t *t_start, int ts,
                                                int *wave_tot) {
     const int tid = threadIdx.x;
@@ -330,12 +366,32 @@ __device__ __forceinline__ void slab_rank_glob(const int32_t *sidx, const uint32
         const uint32_t m = smix[j];
         uint32_t h = m & tmask;
         while (t_key[h] != m) h = (h + 1u) & tmask;
-        const int cnt = t_cnt[h];
-        write_rank(w, T, sidx[j], t_first[h], cnt, bucket + (t_start[h] - cnt));
+        const int cnt = t_cnt[h], idx = sidx[j], f = t_first[h], bs = t_start[h] - cnt;
+        if (idx == f) {
+            w.fb[idx] = (uint8_t)(cnt < T ? cnt : T);
+            if (MEAN && cnt > 1) sorted[bs] = idx;
+        } else {
+            const int r = bucket_rank(bucket + bs, cnt, idx, T);
+            w.fb[idx] = 0;
+            if (!MEAN) w.rec[idx] = make_int2(f, r);
+            else if (r < T) sorted[bs + r] = idx;
+        }
+    }
+    if (MEAN) {
+        __threadfence();
+        __syncthreads();
+        for (int j = tid; j < np; j += SLAB_NT) {
+            const uint32_t m = smix[j];
+            uint32_t h = m & tmask;
+            while (t_key[h] != m) h = (h + 1u) & tmask;
+            const int cnt = t_cnt[h], idx = sidx[j];
+            if (cnt > 1 && idx == t_first[h]) w.tmean[idx] = cell_mean(pts, sorted + (t_start[h] - cnt), cnt < T ? cnt : T);
+        }
     }
 }
 
-__global__ void __launch_bounds__(SLAB_NT) k_slab(int T, int shift, Ws w) {
+template <bool MEAN>
+__global__ void __launch_bounds__(SLAB_NT) k_slab(const float4 *__restrict__ pts, int T, int shift, Ws w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int wave_tot[SLAB_NT / 64];
     __shared__ int l_goff, l_fill;
@@ -350,7 +406,7 @@ __global__ void __launch_bounds__(SLAB_NT) k_slab(int T, int shift, Ws w) {
         int32_t *t_first = t_cnt + SLAB_TS, *t_start = t_first + SLAB_TS;
         int ts = 64;
         while (ts < 2 * np) ts <<= 1;
-        slab_rank_lds(sent, np, T, w, bucket, t_key, t_cnt, t_first, t_start, ts, wave_tot);
+        slab_rank_lds<MEAN>(pts, sent, np, T, w, bucket, t_key, t_cnt, t_first, t_start, ts, wave_tot);
     } else {
         // oversize: gather the slab's points (region + matching overflow entries) into a contiguous global list
         if (tid == 0) { l_goff = atomicAdd(w.galloc, np); l_fill = SLAB_CAP; }
@@ -373,7 +429,7 @@ __global__ void __launch_bounds__(SLAB_NT) k_slab(int T, int shift, Ws w) {
         __syncthreads();
         int ts = 64;
         while (ts < np) ts <<= 1;                // ts < 2 np: tables at [2 goff, 2 goff + 2 np)
-        slab_rank_glob(gi, gm, np, T, w, w.g_bucket + goff, w.g_key + 2 * goff, w.g_cnt + 2 * goff, w.g_first + 2 * goff,
+        slab_rank_glob<MEAN>(pts, w.g_sorted + goff, gi, gm, np, T, w, w.g_bucket + goff, w.g_key + 2 * goff, w.g_cnt + 2 * goff, w.g_first + 2 * goff,
                        w.g_start + 2 * goff, ts, wave_tot);
     }
 }
@@ -534,6 +590,66 @@ __global__ void __launch_bounds__(PLACE_NT) k_place(const float4 *__restrict__ p
     }
 }
 
+// ---- K4': placement of the fused voxelise -> MeanVFE form: one 16-byte feature row per voxel instead of the padded
+// [T, C] block (16 N + M (4 C + 16) bytes).  Same prologue as k_place; every store is dense.
+__global__ void __launch_bounds__(PLACE_NT) k_place_mean(const float4 *__restrict__ pts, int n, Geom g, int n_scenes, int max_voxels,
+                                                         const int32_t *__restrict__ scene_off, Ws w, float4 *__restrict__ feats,
+                                                         int4 *__restrict__ coords_bzyx, int32_t *__restrict__ num_pts,
+                                                         int32_t *__restrict__ scene_voxel_off) {
+    __shared__ int bpre[MAX_KB + 2];
+    __shared__ int l_sfr[MAX_SCENES + 2], l_svo[MAX_SCENES + 2];
+    __shared__ int wave_tot[PLACE_NT / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nwords = (n + 63) >> 6;
+    const int nkb = (n + WORDS_PTS - 1) / WORDS_PTS;
+    const int i = blockIdx.x * PLACE_NT + tid;
+    const bool live = i < n;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    int fbv = 0;
+    if (live) { p = pts[i]; fbv = w.fb[i]; }
+    {
+        const int a0 = 2 * tid < nkb ? w.btot[2 * tid] : 0, a1 = 2 * tid + 1 < nkb ? w.btot[2 * tid + 1] : 0;
+        int tot;
+        const int ex = block_excl_scan(a0 + a1, wave_tot, PLACE_NT / 64, tot);
+        if (2 * tid <= nkb) bpre[2 * tid] = ex;
+        if (2 * tid + 1 <= nkb) bpre[2 * tid + 1] = ex + a0;
+        __syncthreads();
+        for (int s = tid; s <= n_scenes; s += PLACE_NT) {
+            const int si = scene_off[s], wi = si >> 6;
+            l_sfr[s] = wi < nwords ? bpre[wi >> 6] + w.wloc[wi] + popc_below(w.fmask[wi], si & 63) : tot;
+        }
+        __syncthreads();
+        int running = 0;
+        for (int s0 = 0; s0 < n_scenes; s0 += PLACE_NT) {
+            const int s = s0 + tid;
+            int t = 0;
+            if (s < n_scenes) { t = l_sfr[s + 1] - l_sfr[s]; t = t < max_voxels ? t : max_voxels; }
+            int ct;
+            const int e2 = block_excl_scan(t, wave_tot, PLACE_NT / 64, ct);
+            if (s < n_scenes) l_svo[s] = running + e2;
+            running += ct;
+        }
+        if (tid == 0) l_svo[n_scenes] = running;
+        __syncthreads();
+        if (blockIdx.x == 0)
+            for (int s = tid; s <= n_scenes; s += PLACE_NT) scene_voxel_off[s] = l_svo[s];
+    }
+    if (fbv == 0) return;                                            // only first points write
+    const int s = find_scene(scene_off, n_scenes, i);
+    int cc[3];
+    cell_of(p.x, p.y, p.z, g, cc);
+    const unsigned long long fm = __ballot(true);                     // the first points of this wave (all others have left)
+    const int wi = (blockIdx.x * PLACE_NT + wv * 64) >> 6;
+    const int rs = bpre[wi >> 6] + w.wloc[wi] + popc_below(fm, lane) - l_sfr[s];
+    if (rs >= max_voxels) return;
+    const int v = l_svo[s] + rs;
+    // a single-point cell's mean is (0 + p) / 1: the same two operations lvq_mean_vfe performs on its padded row
+    const float4 mean = fbv == 1 ? make_float4((0.f + p.x) / 1.f, (0.f + p.y) / 1.f, (0.f + p.z) / 1.f, (0.f + p.w) / 1.f) : w.tmean[i];
+    feats[v] = mean;
+    num_pts[v] = fbv;
+    coords_bzyx[v] = make_int4(s, cc[2], cc[1], cc[0]);
+}
+
 }  // namespace vh
 
 size_t lvq_hashed_hard_workspace_bytes(int64_t n, int n_scenes) {
@@ -543,13 +659,13 @@ size_t lvq_hashed_hard_workspace_bytes(int64_t n, int n_scenes) {
     return a.s.total();
 }
 
-// `continue` cap semantics, C == 4 payloads, T <= 127, key space < 2^31; anything else -> LVQ_EUNSUPPORTED
-int lvq_hashed_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n, int n_scenes, int c, const float *range_host,
-                             const float *vsize_host, const int32_t *grid_host, int max_pts, int max_voxels, float *voxels,
-                             int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes,
-                             hipStream_t st) {
+// `continue` cap semantics, C == 4 payloads, T <= 127, key space < 2^31; anything else -> LVQ_EUNSUPPORTED.
+// mean != 0: `out` is voxel_features [cap, 4] (voxelise -> MeanVFE fused), else the padded voxels [cap, T, 4].
+static int hashed_voxelize(bool mean, const float *pts, const int32_t *scene_off, int64_t n, int n_scenes, int c, const float *range_host,
+                           const float *vsize_host, const int32_t *grid_host, int max_pts, int max_voxels, float *out,
+                           int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes, hipStream_t st) {
     using namespace vh;
-    if (c != 4 || max_pts > 127 || (((uintptr_t)pts | (uintptr_t)voxels | (uintptr_t)coords_bzyx) & 15)) return LVQ_EUNSUPPORTED;
+    if (c != 4 || max_pts > 127 || (((uintptr_t)pts | (uintptr_t)out | (uintptr_t)coords_bzyx) & 15)) return LVQ_EUNSUPPORTED;
     const int64_t keyspace = (int64_t)n_scenes * grid_host[0] * grid_host[1] * grid_host[2];
     if (keyspace <= 0 || keyspace >= (1ll << 31) - 1 || n > (int64_t)MAX_KB * WORDS_PTS || n_scenes > MAX_SCENES)
         return LVQ_EUNSUPPORTED;
@@ -566,7 +682,8 @@ int lvq_hashed_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t
     for (int j = 0; j < 3; ++j) { g.lo[j] = range_host[j]; g.vs[j] = vsize_host[j]; g.grid[j] = grid_host[j]; }
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute((const void *)k_slab, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute((const void *)k_slab<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute((const void *)k_slab<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
     const unsigned nb = (unsigned)lvq_cdiv(n, BIN_NT * BIN_PPT);
@@ -574,10 +691,31 @@ int lvq_hashed_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t
     hipMemsetAsync(w.cursor, 0, sizeof(int32_t) * (MAX_SLABS + 64), st);
     hipLaunchKernelGGL(k_bin, dim3(nb), dim3(BIN_NT), 2 * sizeof(int32_t) * nslabs, st, p4, (int)n, g, n_scenes, shift, nslabs, scene_off, w);
     const size_t slab_lds = sizeof(int32_t) * SLAB_CAP + 4 * sizeof(int32_t) * SLAB_TS;
-    hipLaunchKernelGGL(k_slab, dim3(nslabs), dim3(SLAB_NT), slab_lds, st, max_pts, shift, w);
+    if (mean) hipLaunchKernelGGL(k_slab<true>, dim3(nslabs), dim3(SLAB_NT), slab_lds, st, p4, max_pts, shift, w);
+    else hipLaunchKernelGGL(k_slab<false>, dim3(nslabs), dim3(SLAB_NT), slab_lds, st, p4, max_pts, shift, w);
     hipLaunchKernelGGL(k_words, dim3((unsigned)lvq_cdiv(n, WORDS_PTS)), dim3(WORDS_NT), 0, st, (int)n, w);
-    hipLaunchKernelGGL(k_place, dim3((unsigned)lvq_cdiv(n, PLACE_NT)), dim3(PLACE_NT), 0, st, p4, (int)n, g, n_scenes, max_pts, max_voxels,
-                       scene_off, w, reinterpret_cast<float4 *>(voxels), reinterpret_cast<int4 *>(coords_bzyx), num_pts,
-                       scene_voxel_off);
+    if (mean)
+        hipLaunchKernelGGL(k_place_mean, dim3((unsigned)lvq_cdiv(n, PLACE_NT)), dim3(PLACE_NT), 0, st, p4, (int)n, g, n_scenes, max_voxels,
+                           scene_off, w, reinterpret_cast<float4 *>(out), reinterpret_cast<int4 *>(coords_bzyx), num_pts, scene_voxel_off);
+    else
+        hipLaunchKernelGGL(k_place, dim3((unsigned)lvq_cdiv(n, PLACE_NT)), dim3(PLACE_NT), 0, st, p4, (int)n, g, n_scenes, max_pts, max_voxels,
+                           scene_off, w, reinterpret_cast<float4 *>(out), reinterpret_cast<int4 *>(coords_bzyx), num_pts,
+                           scene_voxel_off);
     return lvq_launch_status();
+}
+
+int lvq_hashed_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n, int n_scenes, int c, const float *range_host,
+                             const float *vsize_host, const int32_t *grid_host, int max_pts, int max_voxels, float *voxels,
+                             int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes,
+                             hipStream_t st) {
+    return hashed_voxelize(false, pts, scene_off, n, n_scenes, c, range_host, vsize_host, grid_host, max_pts, max_voxels, voxels, coords_bzyx,
+                           num_pts, scene_voxel_off, ws, ws_bytes, st);
+}
+
+int lvq_hashed_voxelize_mean(const float *pts, const int32_t *scene_off, int64_t n, int n_scenes, int c, const float *range_host,
+                             const float *vsize_host, const int32_t *grid_host, int max_pts, int max_voxels, float *voxel_features,
+                             int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes,
+                             hipStream_t st) {
+    return hashed_voxelize(true, pts, scene_off, n, n_scenes, c, range_host, vsize_host, grid_host, max_pts, max_voxels, voxel_features,
+                           coords_bzyx, num_pts, scene_voxel_off, ws, ws_bytes, st);
 }

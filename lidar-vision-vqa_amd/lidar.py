@@ -97,6 +97,36 @@ class VoxelGeneratorWrapper:
         F.check(rc, "lvq_voxelize_hard")
         return voxels, coords, num, svo
 
+    def generate_mean_device(self, points: torch.Tensor, scene_off: torch.Tensor, n_scenes: int):
+        """transform_points_to_voxels + MeanVFE in one call (SURVEY 8d "fused voxelise -> mean"): returns
+        (voxel_features [cap,c], coords_bzyx [cap,4] i32, num_points [cap] i32, scene_voxel_off [S+1] i32), bit-identical to
+        generate_batch_device + MeanVFE.forward_device, without the padded [cap,T,c] tensor.  Shapes the fused kernels do
+        not take run that pair."""
+        F.require_cuda(points, scene_off)
+        assert points.dtype == torch.float32 and scene_off.dtype == torch.int32
+        n, c = points.shape
+        assert c == self.c
+        dev = points.device
+        L = F.lib()
+        if not self.break_on_cap:
+            cap = max(1, min(n, n_scenes * self.max_voxels))
+            feats = torch.empty((cap, c), dtype=torch.float32, device=dev)
+            coords = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+            num = torch.empty((cap,), dtype=torch.int32, device=dev)
+            svo = torch.empty((n_scenes + 1,), dtype=torch.int32, device=dev)
+            nbytes = L.lvq_voxelize_hard_workspace_bytes(F.i64(n), F.cint(n_scenes))
+            ws = workspace(nbytes, dev, getattr(self, "ws_tag", "vox"))
+            rc = L.lvq_voxelize_mean(F.ptr(points), F.ptr(scene_off), F.i64(n), F.cint(n_scenes), F.cint(c), F.f32x(self.range),
+                                     F.f32x(self.vsize), F.i32x(self.grid.tolist()), F.cint(self.t), F.cint(self.max_voxels),
+                                     F.i64(cap), F.ptr(feats), F.ptr(coords), F.ptr(num), F.ptr(svo), F.ptr(ws), F.csize(ws.numel()),
+                                     F.stream_ptr(dev))
+            if rc != -5:                       # LVQ_EUNSUPPORTED: fall through to the two-call route
+                F.check(rc, "lvq_voxelize_mean")
+                return feats, coords, num, svo
+        voxels, coords, num, svo = self.generate_batch_device(points, scene_off, n_scenes)
+        feats = MeanVFE(None, c).forward_device(voxels, num, svo[n_scenes:])
+        return feats, coords, num, svo
+
     def generate(self, points):
         is_np = isinstance(points, np.ndarray)
         dev = self.device or (torch.device("cuda", torch.cuda.current_device()) if is_np else points.device)

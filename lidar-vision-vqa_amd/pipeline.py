@@ -103,8 +103,14 @@ class FusionPipeline(torch.nn.Module):
         side = main if os.environ.get("LVQ_NO_SIDE_STREAM") else self._side
         side.wait_stream(main) if side is not main else None
         with torch.cuda.stream(side):
-            vox3, co3, num3, svo3 = self.gen3d.generate_batch_device(points, scene_off, S)
-            feat3 = self.mean_vfe.forward_device(vox3, num3, svo3[S:])
+            if os.environ.get("LVQ_NO_FUSED_MEAN"):
+                # reference dataflow: padded [M,T,4] voxels, then MeanVFE over them
+                vox3, co3, num3, svo3 = self.gen3d.generate_batch_device(points, scene_off, S)
+                feat3 = self.mean_vfe.forward_device(vox3, num3, svo3[S:])
+            else:
+                # fused voxelise -> mean: bit-identical features, the padded tensor is never written
+                vox3 = None
+                feat3, co3, num3, svo3 = self.gen3d.generate_mean_device(points, scene_off, S)
         # pillar branch -> BEV
         voxp, cop, nump, svop = self.genp.generate_batch_device(points, scene_off, S)
         pf = self.pillar_vfe.forward_device(voxp, nump, cop, svop[S:])
@@ -122,7 +128,8 @@ class FusionPipeline(torch.nn.Module):
         if side is not main:
             main.wait_stream(side)
         for t_ in (vox3, co3, num3, svo3, feat3):
-            t_.record_stream(main)
+            if t_ is not None:
+                t_.record_stream(main)
         return dict(fused=fused, lidar_tokens=lidar_tokens, voxel_features=feat3, voxel_coords=co3, voxel_num_points=num3,
                     scene_voxel_off=svo3, pillar_features=pf, pillar_coords=cop, scene_pillar_off=svop, bev=bev)
 

@@ -147,6 +147,38 @@ def test_hard_voxelizer_hot_cells_among_ordinary_ones():
         assert np.array_equal(gc, oc) and np.array_equal(gn, on) and np.array_equal(gv.view(np.uint32), ov.view(np.uint32))
 
 
+@pytest.mark.parametrize("vs,T,mv", [(synth.VOXEL_01, 10, 60000), (synth.VOXEL_PILLAR, 20, 30000), (synth.VOXEL_PILLAR, 3, 700),
+                                     (synth.VOXEL_PILLAR, 127, 30000)])
+def test_voxelize_mean_is_bit_identical_to_voxelize_plus_mean_vfe(vs, T, mv):
+    """lvq_voxelize_mean (SURVEY 8d fused form, no padded tensor) == lvq_voxelize_hard + lvq_mean_vfe bit for bit, on a ragged
+    batch with an empty scene, unmasked points, cap hits, and cells that overflow a slab region (global ranking path);
+    and == the oracle's MeanVFE on the oracle's voxels."""
+    lid = L()
+    rng = np.random.default_rng(5)
+    hot = np.concatenate((7.0 + rng.uniform(0.0, 0.09, (3000, 2)), rng.uniform(-1.19, -1.01, (3000, 1)), rng.random((3000, 1))),
+                         axis=1).astype(np.float32)
+    s0 = np.concatenate((synth.scene_points("C", 20000, 41), hot))
+    s0 = s0[rng.permutation(len(s0))]
+    scenes = [s0, np.zeros((0, 4), np.float32), synth.scene_points("U", 6001, 42), synth.scene_points("C", 33, 43)]
+    scenes[2][::5, 1] -= 150.0
+    lens = [len(x) for x in scenes]
+    pts = torch.from_numpy(np.concatenate(scenes)).to(DEV)
+    off = torch.tensor(np.concatenate(([0], np.cumsum(lens))), dtype=torch.int32, device=DEV)
+    S = len(scenes)
+    gen = lid.VoxelGeneratorWrapper(vs, RNG, 4, T, mv)
+    vox, co, num, svo = gen.generate_batch_device(pts, off, S)
+    m = int(svo[-1])
+    ref = lid.MeanVFE(None, 4).forward_device(vox, num, svo[S:])[:m]
+    feats, co2, num2, svo2 = gen.generate_mean_device(pts, off, S)
+    assert torch.equal(svo2, svo) and torch.equal(co2[:m], co[:m]) and torch.equal(num2[:m], num[:m])
+    assert np.array_equal(feats[:m].cpu().numpy().view(np.uint32), ref.cpu().numpy().view(np.uint32))
+    exp = []
+    for sc in scenes:
+        v, c, k = LO.VoxelGenerator(vs, RNG, 4, T, mv).generate(sc)
+        exp.append(LO.mean_vfe(v, k))
+    assert np.allclose(feats[:m].cpu().numpy(), np.concatenate(exp), rtol=1e-6, atol=1e-6)
+
+
 def test_hard_voxelizer_all_points_one_voxel():
     """Worst case for the in-bucket ranking: every point in the same cell."""
     rng = np.random.default_rng(3)

@@ -138,6 +138,31 @@ def bench_vox():
         print(f"   dynamic voxelise: {t3 * 1e3:.1f} us  {(20 * bp.shape[0] + M * 16) / t3 / 1e6:.0f} GB/s algorithmic")
 
 
+def bench_bev():
+    """SURVEY 8f rows f2/f3 at the reference's true BEV grid (C=128, 180x180): HBM-bound, algorithmic bytes per call."""
+    from lidar_vision_vqa_amd import bev
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_bev_bridge import synth_sparse
+    B = 16
+    h16 = torch.randn(B, 128, 180, 180, device=DEV).half()
+    out = torch.empty(h16.shape, dtype=torch.float32, device=DEV)
+    t, _ = timeit(lambda: bev.f16_to_f32(h16, out), iters=20)
+    by = h16.numel() * 6
+    print(f"f16->f32 BEV up-cast [{B},128,180,180]: {t * 1e3:.1f} us  {by / t / 1e6:.0f} GB/s ({by / t / 1e6 / 8000:.3f} of 8 TB/s)")
+    for batch, m in [(4, 120000), (16, 480000)]:
+        feats, idx = synth_sparse(4, batch, 5, 180, 180, m, 128)
+        x = bev.SparseTensor(torch.from_numpy(feats).to(DEV), torch.from_numpy(idx).to(DEV), (5, 180, 180), batch)
+        y = bev.bev_out(x)
+        m1, m2 = x.features.shape[0], y.features.shape[0]
+        t, _ = timeit(lambda: bev.bev_out(x), iters=10)
+        by = m1 * (16 + 512) + m2 * (12 + 512)            # indices + features in, unique rows + summed features out
+        print(f"bev_out z-merge B={batch} rows {m1} -> {m2}, C=128: {t * 1e3:.1f} us  {by / t / 1e6:.0f} GB/s algorithmic "
+              f"({by / t / 1e6 / 8000:.3f} of 8 TB/s; includes the zero-fill of the output and one host sync for M2)")
+        t, _ = timeit(lambda: y.dense(), iters=10)
+        by = batch * 128 * 180 * 180 * 4 + m2 * (12 + 512)
+        print(f"   dense() -> [{batch},128,180,180]: {t * 1e3:.1f} us  {by / t / 1e6:.0f} GB/s algorithmic ({by / t / 1e6 / 8000:.3f} of 8 TB/s)")
+
+
 def bench_attn_one():
     """One shape, few launches: the target of `rocprofv3 --pmc`."""
     B, H, nq, nkv, dh = (int(v) for v in os.environ.get("ATTN_SHAPE", "4,12,576,262144,64").split(","))
@@ -165,5 +190,5 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "norm", "vox"]
     for w in which:
         print(f"==== {w} ====")
-        {"gemm": bench_gemm, "attn": bench_attn, "norm": bench_norm, "vox": bench_vox, "attn1": bench_attn_one,
+        {"gemm": bench_gemm, "attn": bench_attn, "norm": bench_norm, "vox": bench_vox, "bev": bench_bev, "attn1": bench_attn_one,
          "gemm1": bench_gemm_one, "projln": bench_projln, "dwconv": bench_dwconv}[w]()
