@@ -97,23 +97,40 @@ __global__ void __launch_bounds__(256) k_map_rows(const int32_t *__restrict__ id
 constexpr int DENSE_CH = 32;
 __global__ void __launch_bounds__(256) k_dense_lines(const float *__restrict__ feats, const int32_t *__restrict__ map, int c, int d, int h,
                                                      int w, float *__restrict__ out) {
-    extern __shared__ float tile[];                 // [DENSE_CH][w + 1]
+    extern __shared__ float tile[];                 // [DENSE_CH][w + 1] | int lmap[w]
     const int line = blockIdx.x;                    // (b * d + z) * h + y
     const int y = line % h, bz = line / h, z = bz % d, b = bz / d;
     const int32_t *mrow = map + (int64_t)line * w;
     const int64_t plane = (int64_t)h * w;
     const int wp = w + 1;
+    int *lmap = reinterpret_cast<int *>(tile + DENSE_CH * wp);
+    for (int x = threadIdx.x; x < w; x += 256) lmap[x] = mrow[x];
+    __syncthreads();
     for (int ch0 = 0; ch0 < c; ch0 += DENSE_CH) {
         const int nch = c - ch0 < DENSE_CH ? c - ch0 : DENSE_CH;
-        for (int e = threadIdx.x; e < w * DENSE_CH; e += 256) {
-            const int x = e / DENSE_CH, k = e % DENSE_CH;           // 32 consecutive lanes read 128 contiguous bytes of one row
-            const int r = mrow[x];
-            tile[k * wp + x] = (r >= 0 && k < nch) ? feats[(int64_t)r * c + ch0 + k] : 0.f;
+        // gather: 32 consecutive lanes read 128 contiguous bytes of one row, 8 rows per sweep, 8 sweeps' loads in flight
+        // (one load per iteration left every iteration waiting on its own L2 / HBM round trip: 219 us instead of ~90)
+        {
+            const int k = threadIdx.x & (DENSE_CH - 1);
+            for (int x0 = threadIdx.x / DENSE_CH; x0 < w; x0 += 64) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int x = x0 + 8 * u;
+                    const int r = x < w ? lmap[x] : -1;
+                    v[u] = (r >= 0 && k < nch) ? feats[(int64_t)r * c + ch0 + k] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int x = x0 + 8 * u;
+                    if (x < w) tile[k * wp + x] = v[u];
+                }
+            }
         }
         __syncthreads();
-        for (int e = threadIdx.x; e < nch * w; e += 256) {
-            const int k = e / w, x = e - k * w;
-            out[(((int64_t)b * c + ch0 + k) * d + z) * plane + (int64_t)y * w + x] = tile[k * wp + x];
+        for (int x = threadIdx.x; x < w; x += 256) {
+            float *dst = out + (((int64_t)b * c + ch0) * d + z) * plane + (int64_t)y * w + x;
+            for (int k = 0; k < nch; ++k) dst[(int64_t)k * d * plane] = tile[k * wp + x];
         }
         __syncthreads();
     }
@@ -212,6 +229,6 @@ extern "C" int lvq_sparse_to_dense(const float *feats, const int32_t *indices, i
     if (m_cap > 0)
         hipLaunchKernelGGL(k_map_rows, dim3((unsigned)lvq_cdiv(m_cap, 256)), dim3(256), 0, st, indices, index_cols, m_cap, n_live_dev, batch, d,
                            h, w, map);
-    hipLaunchKernelGGL(k_dense_lines, dim3((unsigned)lines), dim3(256), sizeof(float) * DENSE_CH * (w + 1), st, feats, map, c, d, h, w, out);
+    hipLaunchKernelGGL(k_dense_lines, dim3((unsigned)lines), dim3(256), sizeof(float) * (DENSE_CH * (w + 1) + w), st, feats, map, c, d, h, w, out);
     return lvq_launch_status();
 }
