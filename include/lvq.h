@@ -80,7 +80,7 @@ int lvq_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n_poin
  * (mean_vfe.py:25-29): voxel_features[m,:] = sum of the first min(count, T) points in input order / that count --
  * the same fp32 additions in the same order as lvq_voxelize_hard + lvq_mean_vfe, hence bit-identical to that pair.
  * coords / num_pts / scene_voxel_off / workspace (lvq_voxelize_hard_workspace_bytes) as for lvq_voxelize_hard.
- * c == 4, T <= 127, key space < 2^31, N <= 8 M, <= 1024 scenes; otherwise LVQ_EUNSUPPORTED (run the pair instead). */
+ * c == 4, T <= 127, key space < 2^31, N <= 4 M, <= 1024 scenes; otherwise LVQ_EUNSUPPORTED (run the pair instead). */
 int lvq_voxelize_mean(const float *pts, const int32_t *scene_off, int64_t n_points, int n_scenes, int c,
                       const float *range_host, const float *vsize_host, const int32_t *grid_host, int max_pts,
                       int max_voxels, int64_t voxel_capacity, float *voxel_features, int32_t *coords_bzyx,

@@ -179,6 +179,27 @@ def test_voxelize_mean_is_bit_identical_to_voxelize_plus_mean_vfe(vs, T, mv):
     assert np.allclose(feats[:m].cpu().numpy(), np.concatenate(exp), rtol=1e-6, atol=1e-6)
 
 
+def test_hard_voxelizer_paths_agree_at_scale(monkeypatch):
+    """BASELINE cfg-4 size x 16 scenes (1.92 M points in one call, max_voxels 160 000): the hash-balanced-slab path and the
+    slab-binned path -- two independent implementations -- agree bit for bit on every output."""
+    lid = L()
+    scenes = [synth.scene_points("C", 120000, 1100 + i) for i in range(4)] * 4
+    pts = torch.from_numpy(np.concatenate(scenes)).to(DEV)
+    off = torch.tensor(np.concatenate(([0], np.cumsum([len(x) for x in scenes]))), dtype=torch.int32, device=DEV)
+    gen = lid.VoxelGeneratorWrapper(synth.VOXEL_01, RNG, 4, 10, 160000)
+    a = gen.generate_batch_device(pts, off, 16)
+    torch.cuda.synchronize()
+    monkeypatch.setenv("LVQ_VOXEL_BINNED", "1")
+    b = gen.generate_batch_device(pts, off, 16)
+    torch.cuda.synchronize()
+    m = int(a[3][-1])
+    assert m > 1000000 and torch.equal(a[3], b[3])
+    assert torch.equal(a[1][:m], b[1][:m]) and torch.equal(a[2][:m], b[2][:m])
+    assert torch.equal(a[0][:m].view(torch.int32), b[0][:m].view(torch.int32))
+    sv = a[3].cpu().numpy()
+    assert np.array_equal(np.diff(sv)[:4], np.diff(sv)[4:8])             # repeated scenes -> repeated per-scene voxel counts
+
+
 def test_hard_voxelizer_all_points_one_voxel():
     """Worst case for the in-bucket ranking: every point in the same cell."""
     rng = np.random.default_rng(3)
@@ -255,6 +276,21 @@ def test_dynamic_voxelize_vs_oracle(dist, n, seed, bs, ndim, vs):
     assert np.array_equal(inv[o["keep"]].astype(np.int64), o["unq_inv"])
     assert np.array_equal(dv["coords"][:m].cpu().numpy(), LO._decode_coords(o["unq_key"], grid, ndim))
     assert np.array_equal(dv["pt_coords"].cpu().numpy()[o["keep"]][:, :ndim], o["coords"][:, :ndim])
+
+
+def test_dynamic_voxelize_16_scenes_large_keys():
+    """Keys above 2^29 (scene index >= 12 on the 0.1 m grid): the key -> (b, z, y, x) decode must stay exact."""
+    bs = 16
+    scenes = [masked("C", 20000, 300 + i) for i in range(bs)]
+    pts = np.concatenate([np.concatenate((np.full((len(s), 1), i, np.float32), s), axis=1) for i, s in enumerate(scenes)])
+    grid = [1024, 1024, 40]
+    o = LO.dynamic_voxelize(pts, RNG, synth.VOXEL_01, grid, 3)
+    dv = L()._dynamic_voxelize(torch.from_numpy(pts).to(DEV), bs, RNG, synth.VOXEL_01, grid, 3)
+    m = int(dv["counts"][0])
+    assert m == len(o["unq_key"]) and int(o["unq_key"].max()) > 2 ** 29
+    assert np.array_equal(dv["unq_key"][:m].cpu().numpy(), o["unq_key"])
+    assert np.array_equal(dv["coords"][:m].cpu().numpy(), LO._decode_coords(o["unq_key"], grid, 3))
+    assert np.array_equal(dv["unq_cnt"][:m].cpu().numpy().astype(np.int64), o["unq_cnt"])
 
 
 def test_dynamic_voxelize_overflow_is_an_error():
