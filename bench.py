@@ -187,7 +187,15 @@ def main():
         torch.cuda.synchronize()
         vus = s.elapsed_time(e) / 20 * 1e3
         vbytes = 16.0 * vpts.shape[0] + m_vox * (4.0 * 10 * 4 + 16)
-        result["voxelise_cfg3"] = {"bound": "hbm", "kernels": "k_bin + k_slab + k_words + k_place (voxel_hashed.hip), whole call", "us": round(vus, 1),
+        vtraffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                for k, v in json.load(f).items():
+                    if k.startswith("lvq_voxelize_hard (voxel_hashed.hip) 8 x 65536 points"):
+                        vtraffic = v["traffic_bytes_per_launch"]        # separate rocprofv3 --pmc passes of the same call (see the file)
+        except Exception:
+            vtraffic = None
+        result["voxelise_cfg3"] = {"bound": "hbm", "traffic": vtraffic, "kernels": "k_bin + k_slab + k_words + k_place (voxel_hashed.hip), whole call", "us": round(vus, 1),
                                    "points": int(vpts.shape[0]), "voxels": m_vox, "achieved": round(vbytes / vus / 1e3, 1), "peak": 8000.0,
                                    "unit": "GB/s", "frac": round(vbytes / vus / 1e3 / 8000.0, 4), "algorithmic_bytes": vbytes}
         del vpts, vout

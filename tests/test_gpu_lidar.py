@@ -387,3 +387,41 @@ def test_pillar_vfe_fast_kernel_flag_combinations(with_distance, abs_xyz, filter
                         list(synth.VOXEL_PILLAR), RNG, filters, True, with_distance, abs_xyz)
     assert (fast - ref).abs().max().item() < 2e-5
     assert (fast - generic).abs().max().item() < 2e-5
+
+
+def test_hard_voxelizer_randomised_sweep():
+    """40 random configurations (grid, T, max_voxels, scene sizes incl. empty ones, point spread, duplicate-heavy clouds) of the
+    default (hash-balanced slab) path against the oracle, per scene, bit for bit."""
+    lid = L()
+    rng = np.random.default_rng(20261004)
+    for trial in range(40):
+        vs = [float(rng.choice([0.1, 0.2, 0.4, 1.6])), float(rng.choice([0.1, 0.2, 0.8])), float(rng.choice([0.2, 2.0, 8.0]))]
+        T = int(rng.choice([1, 2, 5, 10, 32, 127]))
+        mv = int(rng.choice([7, 300, 4000, 60000]))
+        ns = int(rng.integers(1, 7))
+        scenes = []
+        for s in range(ns):
+            n = int(rng.choice([0, 1, 63, 64, 65, 700, 5000, 12000]))
+            kind = rng.integers(0, 3)
+            if kind == 0:
+                p = synth.scene_points("C" if rng.random() < 0.5 else "U", n, int(rng.integers(1, 10 ** 6)))
+            elif kind == 1:                                 # duplicate-heavy: a few hundred distinct positions
+                basep = synth.scene_points("U", max(1, n // 20 + 1), int(rng.integers(1, 10 ** 6)))
+                p = basep[rng.integers(0, len(basep), n)] + rng.normal(0, 0.02, (n, 4)).astype(np.float32)
+            else:                                           # wide spread: most points outside the range
+                p = (rng.normal(0, 80, (n, 4))).astype(np.float32)
+            scenes.append(np.ascontiguousarray(p, dtype=np.float32).reshape(-1, 4))
+        if sum(len(x) for x in scenes) == 0:
+            scenes[0] = synth.scene_points("U", 10, 3)
+        gen = lid.VoxelGeneratorWrapper(vs, RNG, 4, T, mv)
+        bd = lid.voxelize_batch(gen, [torch.from_numpy(x).to(DEV) for x in scenes])
+        svo = bd["scene_voxel_off"].cpu().numpy()
+        co, num, vox = bd["voxel_coords"].cpu().numpy(), bd["voxel_num_points"].cpu().numpy(), bd["voxels"].cpu().numpy()
+        for s, sc in enumerate(scenes):
+            ov, oc, on = LO.VoxelGenerator(vs, RNG, 4, T, mv).generate(sc)
+            a, b = svo[s], svo[s + 1]
+            ctx = f"trial {trial} scene {s} vs={vs} T={T} mv={mv} n={len(sc)}"
+            assert b - a == len(on), ctx
+            assert np.array_equal(co[a:b, 1:], oc) and (co[a:b, 0] == s).all(), ctx
+            assert np.array_equal(num[a:b], on), ctx
+            assert np.array_equal(vox[a:b].view(np.uint32), ov.view(np.uint32)), ctx
