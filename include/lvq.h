@@ -245,6 +245,12 @@ int lvq_rmsnorm(const float *x, const float *gamma, float eps, int64_t rows, int
                 lvq_bf16 *y_lo, lvq_stream_t stream);
 int lvq_rope_inplace(lvq_bf16 *x, lvq_bf16 *x_lo, int64_t rows, int seq_len, int n_heads, int dh, int64_t ld, float theta,
                      lvq_stream_t stream);
+/* decode-time rotary embedding (inference_engine.py:283-296 -> HF generate with a KV cache): the rows are the
+ * new positions pos0 .. pos0 + seq_len - 1 of every sequence (position = pos0 + row % seq_len). */
+int lvq_rope_inplace_at(lvq_bf16 *x, lvq_bf16 *x_lo, int64_t rows, int seq_len, int pos0, int n_heads, int dh, int64_t ld,
+                        float theta, lvq_stream_t stream);
+/* greedy decoding: out_idx[r] = index of the first maximum of x[r, 0..n) (torch.argmax on finite logits). */
+int lvq_argmax_rows(const float *x, int64_t rows, int n, int64_t *out_idx, lvq_stream_t stream);
 int lvq_swiglu(const float *gate_up, int64_t rows, int inter, lvq_bf16 *out_hi, lvq_bf16 *out_lo, lvq_stream_t stream);
 /* sum over rows with labels[row] >= 0 of (logsumexp(logits[row]) - logits[row, label]) and their count:
  * loss = loss_sum_cnt[0] / loss_sum_cnt[1] (transformers causal-LM loss; labels already shifted by the

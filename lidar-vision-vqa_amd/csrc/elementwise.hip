@@ -307,14 +307,14 @@ __global__ void __launch_bounds__(256) k_scale_add_rows(const float *__restrict_
 
 // rotate-half rotary embedding (transformers Qwen2): x[..., :h] , x[..., h:] with angle pos * theta^(-2i/dh)
 __global__ void __launch_bounds__(256) k_rope(uint16_t *__restrict__ xh, uint16_t *__restrict__ xl, int64_t rows, int seq_len,
-                                              int n_heads, int dh, int64_t ld, float theta) {
+                                              int n_heads, int dh, int64_t ld, float theta, int pos0) {
     const int half = dh >> 1;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * n_heads * half) return;
     const int e = (int)(i % half);
     const int hd = (int)((i / half) % n_heads);
     const int64_t row = i / ((int64_t)half * n_heads);
-    const int pos = (int)(row % seq_len);
+    const int pos = pos0 + (int)(row % seq_len);
     const float inv = powf(theta, -2.0f * (float)e / (float)dh);
     float sn, cs;
     sincosf((float)pos * inv, &sn, &cs);
@@ -325,6 +325,32 @@ __global__ void __launch_bounds__(256) k_rope(uint16_t *__restrict__ xh, uint16_
     const uint16_t ha = f32_to_bf16(ra), hb = f32_to_bf16(rb);
     xh[o1] = ha; xh[o2] = hb;
     if (xl) { xl[o1] = f32_to_bf16(ra - bf16_to_f32(ha)); xl[o2] = f32_to_bf16(rb - bf16_to_f32(hb)); }
+}
+
+// one workgroup per row: (value, index) maximum with "smaller index wins" on ties
+__global__ void __launch_bounds__(256) k_argmax_rows(const float *__restrict__ x, int n, int64_t *__restrict__ out) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const float *row = x + (int64_t)blockIdx.x * n;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = row[i];
+        if (v > bv || bi == 0x7fffffff) { bv = v; bi = i; }        // increasing i per thread: ">" keeps the first maximum
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        out[blockIdx.x] = bi == 0x7fffffff ? 0 : bi;
+    }
 }
 
 __global__ void __launch_bounds__(256) k_swiglu(const float *__restrict__ gu, int64_t rows, int inter, uint16_t *__restrict__ oh,
@@ -448,7 +474,28 @@ extern "C" int lvq_rope_inplace(lvq_bf16 *x, lvq_bf16 *x_lo, int64_t rows, int s
     if (!x) return LVQ_EINVAL;
     const int64_t n = rows * n_heads * (dh / 2);
     hipLaunchKernelGGL(k_rope, dim3((unsigned)lvq_cdiv(n, 256)), dim3(256), 0, lvq_s(stream), x, x_lo, rows, seq_len, n_heads,
-                       dh, ld, theta);
+                       dh, ld, theta, 0);
+    return lvq_launch_status();
+}
+
+// decode-time form: the rows are new positions pos0 .. pos0 + seq_len - 1 of every sequence (seq_len = 1: one new token each)
+extern "C" int lvq_rope_inplace_at(lvq_bf16 *x, lvq_bf16 *x_lo, int64_t rows, int seq_len, int pos0, int n_heads, int dh, int64_t ld,
+                                   float theta, lvq_stream_t stream) {
+    if (rows < 0 || seq_len <= 0 || pos0 < 0 || n_heads <= 0 || dh <= 0 || (dh & 1) || ld < (int64_t)n_heads * dh) return LVQ_EINVAL;
+    if (rows == 0) return LVQ_OK;
+    if (!x) return LVQ_EINVAL;
+    const int64_t n = rows * n_heads * (dh / 2);
+    hipLaunchKernelGGL(k_rope, dim3((unsigned)lvq_cdiv(n, 256)), dim3(256), 0, lvq_s(stream), x, x_lo, rows, seq_len, n_heads,
+                       dh, ld, theta, pos0);
+    return lvq_launch_status();
+}
+
+// greedy decoding: index of the first maximum of every row (torch.argmax semantics on finite logits)
+extern "C" int lvq_argmax_rows(const float *x, int64_t rows, int n, int64_t *out_idx, lvq_stream_t stream) {
+    if (rows < 0 || n <= 0) return LVQ_EINVAL;
+    if (rows == 0) return LVQ_OK;
+    if (!x || !out_idx) return LVQ_EINVAL;
+    hipLaunchKernelGGL(k_argmax_rows, dim3((unsigned)rows), dim3(256), 0, lvq_s(stream), x, n, out_idx);
     return lvq_launch_status();
 }
 

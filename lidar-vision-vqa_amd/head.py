@@ -130,39 +130,109 @@ class StandInHead(_HipModule):
         self._packed[key] = (ver, w, b)
         return w, b
 
-    def forward(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
-                labels: Optional[torch.Tensor] = None) -> HeadOutput:
-        self._guard(inputs_embeds)
+    def _layers(self, x: torch.Tensor, B: int, Lq: int, pos0: int = 0, cache=None) -> torch.Tensor:
+        """The decoder stack on rows x [B*Lq, d] = positions pos0 .. pos0+Lq-1 of every sequence.  cache = None: plain causal
+        self-attention over these rows (training-eval path).  cache = list of per-layer ((k_hi, k_lo), (v_hi, v_lo)) buffers
+        [B, Lmax, dkv]: the new keys / values are appended at pos0 and attention runs over positions 0 .. pos0+Lq-1."""
         c = self.cfg
-        B, L, d = inputs_embeds.shape
+        d = c["d"]
         H, Hk, dh = c["n_heads"], c["n_kv_heads"], self.dh
         dkv = dh * Hk
         split = self._split()
-        x = _f32(inputs_embeds).view(B * L, d)
         ld = d + 2 * dkv
+        sl = lambda t, c0: (t[0][:, c0:], None if t[1] is None else t[1][:, c0:])
         for i, layer in enumerate(self.model.layers):
             a = layer.self_attn
             h = ops.rmsnorm(x, layer.input_layernorm.weight, c["rms_eps"], split)
             wqkv, bqkv = self._pack(("qkv", i), (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight),
                                     (a.q_proj.bias, a.k_proj.bias, a.v_proj.bias))
             _, qkv = ops.linear(h, wqkv, bqkv, out_bf=True)
-            sl = lambda t, c0: (t[0][:, c0:], None if t[1] is None else t[1][:, c0:])
-            ops.rope_inplace(sl(qkv, 0), B * L, L, H, dh, ld, c["rope_theta"])
-            ops.rope_inplace(sl(qkv, d), B * L, L, Hk, dh, ld, c["rope_theta"])
-            st = (L * ld, ld, dh)
-            o = ops.attention(sl(qkv, 0), sl(qkv, d), sl(qkv, d + dkv), batch=B, n_heads=H, n_kv_heads=Hk, nq=L, nkv=L, dh=dh,
-                              q_strides=st, k_strides=st, v_strides=st, scale=1.0 / math.sqrt(dh), causal=True)
+            ops.rope_inplace(sl(qkv, 0), B * Lq, Lq, H, dh, ld, c["rope_theta"], pos0)
+            ops.rope_inplace(sl(qkv, d), B * Lq, Lq, Hk, dh, ld, c["rope_theta"], pos0)
+            st = (Lq * ld, ld, dh)
+            if cache is None:
+                o = ops.attention(sl(qkv, 0), sl(qkv, d), sl(qkv, d + dkv), batch=B, n_heads=H, n_kv_heads=Hk, nq=Lq, nkv=Lq, dh=dh,
+                                  q_strides=st, k_strides=st, v_strides=st, scale=1.0 / math.sqrt(dh), causal=True)
+            else:
+                kc, vc = cache[i]
+                lmax = kc[0].shape[1]
+                for part in (0, 1):                       # hi (and lo in the bf16x3 mode): byte movement into the cache
+                    if qkv[part] is None:
+                        continue
+                    rows = qkv[part].view(B, Lq, ld)
+                    kc[part][:, pos0:pos0 + Lq].copy_(rows[:, :, d:d + dkv])
+                    vc[part][:, pos0:pos0 + Lq].copy_(rows[:, :, d + dkv:])
+                cs = (lmax * dkv, dkv, dh)
+                o = ops.attention(sl(qkv, 0), kc, vc, batch=B, n_heads=H, n_kv_heads=Hk, nq=Lq, nkv=pos0 + Lq, dh=dh,
+                                  q_strides=st, k_strides=cs, v_strides=cs, scale=1.0 / math.sqrt(dh), causal=Lq > 1)
             x, _ = ops.linear(o, self._w(a.o_proj.weight), None, residual=x, out_f32=True)
             h = ops.rmsnorm(x, layer.post_attention_layernorm.weight, c["rms_eps"], split)
             wgu, _ = self._pack(("gu", i), (layer.mlp.gate_proj.weight, layer.mlp.up_proj.weight))
             gu, _ = ops.linear(h, wgu, None, out_f32=True)
             act = ops.swiglu(gu, split)
             x, _ = ops.linear(act, self._w(layer.mlp.down_proj.weight), None, residual=x, out_f32=True)
-        hf = ops.rmsnorm(x, self.model.norm.weight, c["rms_eps"], split)
+        return x
+
+    def _logits(self, x: torch.Tensor) -> torch.Tensor:
+        hf = ops.rmsnorm(x, self.model.norm.weight, self.cfg["rms_eps"], self._split())
         logits, _ = ops.linear(hf, self._w(self.model.embed_tokens.weight), None, out_f32=True)
+        return logits
+
+    def forward(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                labels: Optional[torch.Tensor] = None) -> HeadOutput:
+        self._guard(inputs_embeds)
+        B, L, d = inputs_embeds.shape
+        x = self._layers(_f32(inputs_embeds).view(B * L, d), B, L)
+        logits = self._logits(x)
         loss = None
         if labels is not None:
             shifted = torch.full_like(labels, -100)
             shifted[:, :-1] = labels[:, 1:]
             loss = ops.cross_entropy(logits, shifted.reshape(-1).contiguous())
         return HeadOutput(logits.view(B, L, -1), loss)
+
+    @torch.no_grad()
+    def generate(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, max_new_tokens: int = 64,
+                 do_sample: bool = False, num_beams: int = 1, pad_token_id: Optional[int] = None,
+                 eos_token_id: Optional[int] = None, output_scores: bool = False, **unused):
+        """`base_model.generate(inputs_embeds=, attention_mask=, max_new_tokens=, do_sample=False, num_beams=1, pad_token_id=,
+        eos_token_id=)` as inference_engine.py:283-296 calls it: greedy decoding with a per-layer KV cache.  Returns the NEW
+        token ids [B, n] (what transformers returns when only inputs_embeds is given); with output_scores=True also the
+        per-step logits [B, n, V].  Sampling / beam search are not built (the reference's defaults do_sample=True,
+        temperature=0.7 draw from torch's RNG; pass do_sample=False for the deterministic path)."""
+        self._guard(inputs_embeds)
+        if do_sample or num_beams != 1:
+            raise F.LvqError("StandInHead.generate implements greedy decoding only (do_sample=False, num_beams=1)")
+        if attention_mask is not None and not bool((attention_mask == 1).all()):
+            raise F.LvqError("StandInHead.generate expects an all-ones attention_mask (the reference builds exactly that)")
+        c = self.cfg
+        B, L, d = inputs_embeds.shape
+        dkv = self.dh * c["n_kv_heads"]
+        dev = inputs_embeds.device
+        lmax = L + max_new_tokens
+        split = self._split()
+        mk = lambda: (torch.empty((B, lmax, dkv), dtype=torch.bfloat16, device=dev),
+                      torch.empty((B, lmax, dkv), dtype=torch.bfloat16, device=dev) if split else None)
+        cache = [(mk(), mk()) for _ in self.model.layers]
+        x = self._layers(_f32(inputs_embeds).view(B * L, d), B, L, 0, cache)          # prefill
+        step_logits = self._logits(x.view(B, L, d)[:, -1].contiguous())                 # [B, V]
+        pad = 0 if pad_token_id is None else int(pad_token_id)
+        unfinished = torch.ones(B, dtype=torch.bool, device=dev)
+        ids, scores = [], []
+        for t in range(max_new_tokens):
+            nxt = ops.argmax_rows(step_logits)
+            if eos_token_id is not None:
+                nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
+            ids.append(nxt)
+            if output_scores:
+                scores.append(step_logits)
+            if eos_token_id is not None:
+                unfinished = unfinished & (nxt != int(eos_token_id))
+                if not bool(unfinished.any()):                                          # host sync, as in transformers' loop
+                    break
+            if t + 1 == max_new_tokens:
+                break
+            x = self._layers(self.embed(nxt).float().contiguous(), B, 1, L + t, cache)
+            step_logits = self._logits(x)
+        out = torch.stack(ids, dim=1)
+        return (out, torch.stack(scores, dim=1)) if output_scores else out

@@ -212,12 +212,26 @@ def scale_add_rows(x: torch.Tensor, add: Optional[torch.Tensor], alpha: float = 
     return out
 
 
-def rope_inplace(x: BF, rows: int, seq_len: int, n_heads: int, dh: int, ld: int, theta: float):
-    """Rotary embedding applied in place to a (column slice of a) packed projection; position = row % seq_len."""
+def rope_inplace(x: BF, rows: int, seq_len: int, n_heads: int, dh: int, ld: int, theta: float, pos0: int = 0):
+    """Rotary embedding applied in place to a (column slice of a) packed projection; position = pos0 + row % seq_len."""
     hi, lo = x
+    if pos0:
+        rc = F.lib().lvq_rope_inplace_at(F.ptr(hi), F.ptr(lo), F.i64(rows), F.cint(seq_len), F.cint(pos0), F.cint(n_heads), F.cint(dh),
+                                         F.i64(ld), F.cfloat(theta), F.stream_ptr(hi.device))
+        F.check(rc, "lvq_rope_inplace_at")
+        return
     rc = F.lib().lvq_rope_inplace(F.ptr(hi), F.ptr(lo), F.i64(rows), F.cint(seq_len), F.cint(n_heads), F.cint(dh), F.i64(ld),
                                   F.cfloat(theta), F.stream_ptr(hi.device))
     F.check(rc, "lvq_rope_inplace")
+
+
+def argmax_rows(x: torch.Tensor) -> torch.Tensor:
+    """[rows, n] fp32 -> [rows] int64, first maximum of every row (greedy decoding)."""
+    F.require_cuda(x)
+    rows, n = x.shape
+    out = torch.empty((rows,), dtype=torch.int64, device=x.device)
+    F.check(F.lib().lvq_argmax_rows(F.ptr(x), F.i64(rows), F.cint(n), F.ptr(out), F.stream_ptr(x.device)), "lvq_argmax_rows")
+    return out
 
 
 def swiglu(gate_up: torch.Tensor, split: bool) -> BF:

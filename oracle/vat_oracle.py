@@ -228,3 +228,30 @@ def qwen2_head(inputs_embeds: torch.Tensor, sd: SD, cfg: dict, labels: Optional[
         loss = F.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]).float(), labels[:, 1:].reshape(-1),
                                ignore_index=-100)
     return logits, loss
+
+
+def qwen2_generate(inputs_embeds: torch.Tensor, sd: SD, cfg: dict, max_new_tokens: int, eos_token_id: Optional[int] = None,
+                   pad_token_id: int = 0):
+    """Greedy decoding as `base_model.generate(inputs_embeds=, do_sample=False, num_beams=1)` runs it
+    (inference/inference_engine.py:283-296): returns (new token ids [B, n], per-step logits [B, n, V]).  Every step
+    recomputes the whole sequence (no KV cache -- the oracle is the checker, not the thing measured).  A finished
+    sequence emits pad_token_id; decoding stops when every sequence has emitted eos_token_id."""
+    x = inputs_embeds
+    B = x.shape[0]
+    E = sd["model.embed_tokens.weight"]
+    ids, scores = [], []
+    unfinished = torch.ones(B, dtype=torch.bool)
+    for _ in range(max_new_tokens):
+        logits, _ = qwen2_head(x, sd, cfg)
+        step = logits[:, -1]
+        nxt = step.argmax(-1)
+        if eos_token_id is not None:
+            nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad_token_id))
+        ids.append(nxt)
+        scores.append(step)
+        if eos_token_id is not None:
+            unfinished = unfinished & (nxt != eos_token_id)
+            if not bool(unfinished.any()):
+                break
+        x = torch.cat((x, E[nxt].unsqueeze(1)), dim=1)
+    return torch.stack(ids, dim=1), torch.stack(scores, dim=1)

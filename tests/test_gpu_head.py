@@ -55,3 +55,38 @@ def test_prefix_assembly_and_answer_logits(prec, tol):
         tol = 2e-2 * float(np.abs(g["answer_logits"]).max())
     assert err < tol, err                                                                     # north_star: answer logits within 1e-3
     assert abs(float(out.loss) - float(g["loss"])) < tol
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 1e-3), ("bf16", None)])
+def test_greedy_generate_vs_transformers(prec, tol):
+    """SURVEY 8f row f4 (inference_engine.py:283-296): greedy decoding with the KV cache == transformers'
+    `generate(inputs_embeds=, do_sample=False)` on the seeded Qwen2 stand-in: token ids exactly (the golden top-1 / top-2
+    margin is 0.11), per-step logits within the precision mode's bound, EOS / pad handling, argmax kernel."""
+    from lidar_vision_vqa_amd import head, ops, _ffi
+    hc = cases.HEAD_CASE
+    g, gp = golden("head_generate"), golden("head_prefix")
+    base = build(hc, prec)[0]
+    inp = torch.from_numpy(gp["inputs_embeds"])[:, :-hc["n_answer"]].contiguous().to(DEV)
+    attn = torch.ones(inp.shape[:2], dtype=torch.long, device=DEV)
+    n = g["ids"].shape[1]
+    ids, scores = base.generate(inputs_embeds=inp, attention_mask=attn, max_new_tokens=n, do_sample=False, num_beams=1,
+                                pad_token_id=0, eos_token_id=None, output_scores=True)
+    assert ids.dtype == torch.int64 and tuple(ids.shape) == g["ids"].shape
+    if tol is None:
+        tol = 2e-2 * float(np.abs(g["scores"]).max())
+    assert np.abs(scores.cpu().numpy() - g["scores"]).max() < tol
+    assert np.array_equal(ids.cpu().numpy(), g["ids"])
+    # the cached decode steps agree with a full forward over prompt + generated tokens (no cache)
+    with torch.no_grad():
+        full = torch.cat((inp, base.embed(ids[:, :-1])), dim=1)
+        ref = base(inputs_embeds=full).logits[:, inp.shape[1] - 1:]
+    assert (ref - scores).abs().max().item() < (1e-3 if prec == "bf16x3" else tol)
+    ids2 = base.generate(inputs_embeds=inp, attention_mask=attn, max_new_tokens=n, do_sample=False, pad_token_id=0,
+                         eos_token_id=int(g["eos"]))
+    assert np.array_equal(ids2.cpu().numpy(), g["ids_eos"])
+    with pytest.raises(_ffi.LvqError):
+        base.generate(inputs_embeds=inp, do_sample=True)
+    x = torch.tensor([[1.0, 5.0, 5.0, -2.0], [-3.0, -3.0, -7.0, -3.0]], device=DEV)
+    assert ops.argmax_rows(x).cpu().tolist() == [1, 0]                     # first maximum
+    big = torch.randn(7, 151936, device=DEV)
+    assert torch.equal(ops.argmax_rows(big), big.argmax(-1))               # Qwen2.5 vocabulary width

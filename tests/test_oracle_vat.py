@@ -161,3 +161,19 @@ def test_prefix_and_head():
     ref = torch.from_numpy(g["answer_logits"])
     assert (logits[:, -hc["n_answer"]:] - ref).abs().max().item() < 1e-4
     assert abs(loss.item() - float(g["loss"])) < 1e-4
+
+
+def test_greedy_generate_matches_transformers():
+    """the oracle's greedy loop == transformers' `generate(inputs_embeds=, do_sample=False)` on the seeded
+    Qwen2 stand-in (tools/make_generate_golden.py): token ids exactly, per-step logits within 1e-4, EOS / pad handling."""
+    hc = cases.HEAD_CASE
+    g, gp = golden("head_generate"), golden("head_prefix")
+    hs = head_state(hc)
+    inp = torch.from_numpy(gp["inputs_embeds"])[:, :-hc["n_answer"]]
+    assert inp.shape[1] == int(g["n_prompt_positions"])
+    n = g["ids"].shape[1]
+    ids, scores = VO.qwen2_generate(inp, hs, hc, n)
+    assert np.array_equal(ids.numpy(), g["ids"])
+    assert np.abs(scores.numpy() - g["scores"]).max() < 1e-4
+    ids2, _ = VO.qwen2_generate(inp, hs, hc, n, eos_token_id=int(g["eos"]), pad_token_id=0)
+    assert np.array_equal(ids2.numpy(), g["ids_eos"])
