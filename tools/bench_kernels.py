@@ -167,6 +167,32 @@ def bench_bev():
         print(f"   dense() -> [{batch},128,180,180]: {t * 1e3:.1f} us  {by / t / 1e6:.0f} GB/s algorithmic ({by / t / 1e6 / 8000:.3f} of 8 TB/s)")
 
 
+def bench_decode():
+    """SURVEY 8f f4 at the reference's true decoder size (Qwen2.5-0.5B geometry, random weights): prefill of the multimodal prompt
+    (2 + 576 + 2 + 258 + 32 prompt positions) and greedy decode steps with the KV cache."""
+    from lidar_vision_vqa_amd import head
+    B, L, n_new = 1, 870, 32
+    base = head.StandInHead(151936, 896, 4864, 14, 2, 24, 1e-6, 1000000.0).to(DEV).eval()
+    for p in base.parameters():
+        p.data.normal_(0, 0.02)
+    for prec in ("bf16", "bf16x3"):
+        base.precision = prec
+        inp = torch.randn(B, L, 896, device=DEV) * 0.05
+        base.generate(inputs_embeds=inp, max_new_tokens=4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        base.generate(inputs_embeds=inp, max_new_tokens=1)
+        torch.cuda.synchronize()
+        t_pre = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        base.generate(inputs_embeds=inp, max_new_tokens=n_new)
+        torch.cuda.synchronize()
+        t_all = time.perf_counter() - t0
+        per = (t_all - t_pre) / (n_new - 1)
+        print(f"decode {prec}: prefill L={L}: {t_pre * 1e3:.1f} ms; {per * 1e3:.2f} ms/token ({1 / per:.0f} tokens/s, B={B}; "
+              f"24 layers x ~14 launches per token: launch-bound, no hipGraph yet)")
+
+
 def bench_attn_one():
     """One shape, few launches: the target of `rocprofv3 --pmc`."""
     B, H, nq, nkv, dh = (int(v) for v in os.environ.get("ATTN_SHAPE", "4,12,576,262144,64").split(","))
@@ -194,5 +220,5 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "norm", "vox"]
     for w in which:
         print(f"==== {w} ====")
-        {"gemm": bench_gemm, "attn": bench_attn, "norm": bench_norm, "vox": bench_vox, "bev": bench_bev, "attn1": bench_attn_one,
+        {"gemm": bench_gemm, "attn": bench_attn, "norm": bench_norm, "vox": bench_vox, "bev": bench_bev, "decode": bench_decode, "attn1": bench_attn_one,
          "gemm1": bench_gemm_one, "projln": bench_projln, "dwconv": bench_dwconv}[w]()
