@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(_HERE, "liblvq_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lvq.h")
 
 LVQ_OK = 0
+LVQ_EUNSUPPORTED = -5      # include/lvq.h: shape outside what a kernel family implements (callers may pick another route)
 
 
 class LvqError(RuntimeError):

@@ -120,7 +120,7 @@ class VoxelGeneratorWrapper:
                                      F.f32x(self.vsize), F.i32x(self.grid.tolist()), F.cint(self.t), F.cint(self.max_voxels),
                                      F.i64(cap), F.ptr(feats), F.ptr(coords), F.ptr(num), F.ptr(svo), F.ptr(ws), F.csize(ws.numel()),
                                      F.stream_ptr(dev))
-            if rc != -5:                       # LVQ_EUNSUPPORTED: fall through to the two-call route
+            if rc != F.LVQ_EUNSUPPORTED:       # unsupported shape: fall through to the two-call route
                 F.check(rc, "lvq_voxelize_mean")
                 return feats, coords, num, svo
         voxels, coords, num, svo = self.generate_batch_device(points, scene_off, n_scenes)
