@@ -167,6 +167,28 @@ def bench_bev():
         print(f"   dense() -> [{batch},128,180,180]: {t * 1e3:.1f} us  {by / t / 1e6:.0f} GB/s algorithmic ({by / t / 1e6 / 8000:.3f} of 8 TB/s)")
 
 
+def bench_ca():
+    """Every cross-attention row of SURVEY 8d through VATBlock.cross_attention (ca_ln -> Q / K|V projections -> attention -> out
+    projection + residual); FLOPs per scene = 4 Nq d^2 + 4 Nkv d^2 + 4 Nq Nkv d."""
+    from lidar_vision_vqa_amd import fusion
+    rows = [("32k pts x 196 patches (headline)", 1, 32768, 196, 768, 12), ("resampled LiDAR tokens x patches", 1, 576, 196, 768, 12),
+            ("resampled LiDAR tokens x patches", 8, 576, 196, 768, 12), ("cfg-5", 8, 256, 576, 768, 12),
+            ("reference-true VATLiDAR (head_dim 112)", 1, 576, 32400, 896, 8), ("reference-true VATVision (head_dim 256)", 1, 768, 1536, 2048, 8)]
+    if os.environ.get("CA_ROW"):                      # one row only: the target of `rocprofv3 --kernel-trace --stats`
+        rows = [rows[int(os.environ["CA_ROW"])]]
+    print(f"{'row':>42} {'B':>3} {'Nq':>6} {'Nkv':>6} {'d':>5} {'h':>3} {'mode':>7} {'ms':>8} {'TFLOP/s':>8} {'frac':>6}")
+    for what, B, nq, nkv, d, h in rows:
+        blk = synth.load_seeded(fusion.VATBlock(d, h, 4 * d, 0.1).to(DEV).eval(), 5)
+        q = torch.randn(B, nq, d, device=DEV)
+        kv = torch.randn(B, nkv, d, device=DEV)
+        fl = B * (4.0 * nq * d * d + 4.0 * nkv * d * d + 4.0 * nq * nkv * d)
+        for prec in ("bf16", "bf16x3"):
+            blk.precision = prec
+            t, _ = timeit(lambda: blk.cross_attention(q, kv), iters=10)
+            print(f"{what:>42} {B:>3} {nq:>6} {nkv:>6} {d:>5} {h:>3} {prec:>7} {t:8.4f} {fl / t / 1e9:8.1f} {fl / t / 1e9 / 2500:6.3f}")
+        del blk, q, kv
+
+
 def bench_decode():
     """SURVEY 8f f4 at the reference's true decoder size (Qwen2.5-0.5B geometry, random weights): prefill of the multimodal prompt
     (2 + 576 + 2 + 258 + 32 prompt positions) and greedy decode steps with the KV cache."""
@@ -220,5 +242,5 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "norm", "vox"]
     for w in which:
         print(f"==== {w} ====")
-        {"gemm": bench_gemm, "attn": bench_attn, "norm": bench_norm, "vox": bench_vox, "bev": bench_bev, "decode": bench_decode, "attn1": bench_attn_one,
+        {"gemm": bench_gemm, "attn": bench_attn, "norm": bench_norm, "vox": bench_vox, "bev": bench_bev, "decode": bench_decode, "ca": bench_ca, "attn1": bench_attn_one,
          "gemm1": bench_gemm_one, "projln": bench_projln, "dwconv": bench_dwconv}[w]()
