@@ -964,8 +964,20 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, 
     // doubled the kernel time (4 ms vs 8 ms run to run)
     int ns = (int)((4096 + base - 1) / base);
     if (ns > n_tiles / 8) ns = n_tiles / 8;            // at least 8 KV tiles per split
+    // head_dim 96 / 128: a partial is (dh + 2) fp32 per query and split -- with the 5-round rule the partials of the reference's
+    // own VATLiDAR geometry (576 x 32 400, head_dim 112, 8 heads: 63 splits) were 132 MB against 116 MB of K|V.  One full
+    // round of workgroups is enough there (measured: 63 splits 0.481 ms, 32: 0.416, 19: 0.395, 12: 0.392, 8: 0.466 for the
+    // whole cross-attention sub-path).
+    if (dhp >= 96) {
+        const int64_t one_round = (256 * 3) / base;
+        if (one_round >= 1 && ns > one_round) ns = (int)one_round;
+    }
     if (ns < 1) ns = 1;
     if (ns > 64) ns = 64;
+    if (const char *ev = getenv("LVQ_ATTN_NSPLIT")) {           // test / tuning hook, as for k_attn32
+        const int f = atoi(ev);
+        if (f >= 1 && f <= 64 && f <= n_tiles) ns = f;
+    }
     p.nsplit = ns;
     return p;
 }
