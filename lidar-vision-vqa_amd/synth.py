@@ -84,3 +84,47 @@ def load_seeded(module, seed: int):
     new = {k: torch.from_numpy(seeded_array(k, tuple(v.shape), seed)).to(v.dtype) for k, v in sd.items()}
     module.load_state_dict(new)
     return module
+
+
+class DummyTokenizer:
+    """Character-level stand-in for the Qwen tokenizer (fetched by name in the reference, unavailable offline) with the four
+    members inference_engine.py touches: __call__(prompt, return_tensors="pt", add_special_tokens=False)["input_ids"],
+    convert_tokens_to_ids, decode(ids, skip_special_tokens=True), pad_token_id / eos_token_id.  Ids 0..3 are the special
+    tokens <vision_start> <vision_end> <lidar_start> <lidar_end> (the rows assemble_prefix uses); other characters map
+    to 4 + ord(c) % (vocab - 4)."""
+    SPECIALS = ("<vision_start>", "<vision_end>", "<lidar_start>", "<lidar_end>")
+
+    def __init__(self, vocab: int, eos_token_id=None, pad_token_id: int = 0):
+        self.vocab = int(vocab)
+        self.eos_token_id = eos_token_id
+        self.pad_token_id = pad_token_id
+
+    def convert_tokens_to_ids(self, tok: str) -> int:
+        return self.SPECIALS.index(tok)
+
+    def encode(self, text: str):
+        ids, i = [], 0
+        while i < len(text):
+            for k, sp in enumerate(self.SPECIALS):
+                if text.startswith(sp, i):
+                    ids.append(k)
+                    i += len(sp)
+                    break
+            else:
+                ids.append(4 + ord(text[i]) % (self.vocab - 4))
+                i += 1
+        return ids
+
+    def __call__(self, text: str, return_tensors: str = "pt", add_special_tokens: bool = False):
+        import torch
+        return {"input_ids": torch.tensor([self.encode(text)], dtype=torch.long)}
+
+    def decode(self, ids, skip_special_tokens: bool = True) -> str:
+        out = []
+        for t in [int(v) for v in ids]:
+            if t < 4:
+                if not skip_special_tokens:
+                    out.append(self.SPECIALS[t])
+            else:
+                out.append(chr(32 + (t - 4) % 95))          # printable ASCII
+        return "".join(out)

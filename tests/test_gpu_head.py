@@ -90,3 +90,42 @@ def test_greedy_generate_vs_transformers(prec, tol):
     assert ops.argmax_rows(x).cpu().tolist() == [1, 0]                     # first maximum
     big = torch.randn(7, 151936, device=DEV)
     assert torch.equal(ops.argmax_rows(big), big.argmax(-1))               # Qwen2.5 vocabulary width
+
+
+@pytest.mark.parametrize("prec", ["bf16x3", "bf16"])
+def test_inference_engine_vs_unmodified_reference(prec, tmp_path):
+    """engine.InferenceEngine (format_prompt / process_lidar / build_inputs_embeds / generate / generate_batch)
+    against goldens produced by the UNMODIFIED reference InferenceEngine class on CPU (tools/make_engine_golden.py)."""
+    from lidar_vision_vqa_amd import engine, bev as BV
+    hc = cases.HEAD_CASE
+    g = golden("engine")
+    base, vl, va, vv = build(hc, prec)
+    tok = synth.DummyTokenizer(hc["vocab"])
+    question, system = "How many cars are ahead of the ego vehicle?", "You are a driving assistant."
+    tol = 1e-3 if prec == "bf16x3" else 2e-2
+    views = [torch.from_numpy(synth.randn((8, 64), hc["seed"] + 50 + v)) for v in range(6)]
+    bev = synth.randn((16, 10, 10), hc["seed"] + 40)
+    for tag, use_vision in (("l", False), ("v", True)):
+        models = dict(tokenizer=tok, base_model=base, vat_lidar=vl, vat_vision=vv if use_vision else None, vision_adapter=va,
+                      multiview_tokens_fn=lambda sample_token: views, device=torch.device(DEV), d_model=hc["d"],
+                      config=dict(use_vision=use_vision, prefix_scale=0.2, system_prompt=system if use_vision else ""))
+        eng = engine.InferenceEngine(models)
+        prompt = eng.format_prompt(question, include_vision=use_vision)
+        assert tok.encode(prompt) == g[f"{tag}_prompt_ids"].tolist()
+        lp = eng.process_lidar(torch.from_numpy(bev))
+        vp = eng.process_vision("sample-token") if use_vision else None
+        emb, attn = eng.build_inputs_embeds(prompt, lp, vp)
+        assert tuple(emb.shape) == g[f"{tag}_inputs_embeds"].shape and bool((attn == 1).all())
+        assert np.abs(emb.cpu().numpy() - g[f"{tag}_inputs_embeds"]).max() < tol
+        n = g[f"{tag}_ids"].shape[1]
+        want = tok.decode(g[f"{tag}_ids"][0]).strip()
+        ans = eng.generate(question, bev, sample_token="sample-token" if use_vision else None, max_new_tokens=n, do_sample=False)
+        assert ans == want and len(ans) == n          # the reference itself returns "" here (slice quirk, see engine.py)
+    # stored fp16 BEV by path (np.load + .float() in the reference), and the batch form
+    p = tmp_path / "tok.npy"
+    BV.save_bev_feature(p, bev)
+    eng = engine.InferenceEngine(dict(tokenizer=tok, base_model=base, vat_lidar=vl, device=torch.device(DEV), d_model=hc["d"],
+                                      config=dict(use_vision=False, prefix_scale=0.2)))
+    a = eng.generate_batch([question, question], [str(p), bev.astype(np.float16)], max_new_tokens=4, do_sample=False)
+    assert len(a) == 2 and a[0] == a[1] and len(a[0]) == 4
+    assert int(g["l_reference_answer_is_empty"]) == 1
