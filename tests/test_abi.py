@@ -91,3 +91,26 @@ def test_default_init_matches_reference_rng_order():
     torch.manual_seed(123)
     ln1 = nn.LayerNorm(64); sa = nn.MultiheadAttention(64, 4, dropout=0.1, batch_first=True)
     assert torch.equal(ours.sa.in_proj_weight, sa.in_proj_weight)
+
+
+def test_committed_bench_line_keeps_the_driver_contract():
+    """profiles/r01_bench_final.json is the line `python bench.py` printed on the MI355X for the committed build: the fields the
+    driver and the judge read must all be there (bench.py contract: metric / value / roofline / cpu_baseline ...)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_bench_final.json")) as f:
+        d = json.load(f)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "BASELINE.json")) as f:
+        base = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"].replace("x", "×") == base["metric"].replace("x", "×") or d["metric"][:30] == base["metric"][:30]
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert abs(d["value"] - d["config"]["scenes_per_gpu_per_step"] * d["config"]["fused_tokens_per_scene"] / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]
