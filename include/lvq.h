@@ -289,6 +289,32 @@ size_t lvq_sparse_to_dense_workspace_bytes(int batch, int d, int h, int w);
 int lvq_sparse_to_dense(const float *feats, const int32_t *indices, int index_cols, int64_t m_cap, const int32_t *n_live_dev,
                         int c, int batch, int d, int h, int w, float *out, void *ws, size_t ws_bytes, lvq_stream_t stream);
 
+/* =====================================================================================
+ * Decode-step runtime
+ * ===================================================================================== */
+
+/* One greedy-decoding step of the Qwen2-architecture decoder (inference_engine.py:283-296 -> transformers generate with a KV
+ * cache) as ONE native call: per layer RMSNorm -> packed q|k|v projection (+bias) -> rotary embedding at position `pos` ->
+ * append K, V to the caches -> attention of the one new query over positions 0..pos -> o_proj + residual -> RMSNorm ->
+ * gate|up projection -> SiLU(gate)*up -> down projection + residual.  The same kernels, order and arguments as the
+ * Python loop of head.StandInHead (bit-identical), without ~14 ctypes round trips per layer.
+ *   x [batch, d] fp32: embedding of the new token in, hidden state out (final norm + lm head are the caller's)
+ *   layers: HOST array of n_layers structs of DEVICE pointers; weights are bf16 (hi) with optional lo parts (precision 3)
+ *   caches [batch, lmax, dkv] bf16 (post-rotary keys); pos < lmax; precision: 1 = bf16, 3 = bf16x3 */
+typedef struct {
+    const float *ln1, *ln2;                       /* input_layernorm / post_attention_layernorm weights [d] */
+    const lvq_bf16 *wqkv, *wqkv_lo;               /* [d + 2 dkv, d]  (q_proj | k_proj | v_proj rows) */
+    const float *bqkv;                            /* [d + 2 dkv] */
+    const lvq_bf16 *wo, *wo_lo;                   /* [d, d] */
+    const lvq_bf16 *wgu, *wgu_lo;                 /* [2 inter, d]    (gate_proj | up_proj rows) */
+    const lvq_bf16 *wdown, *wdown_lo;             /* [d, inter] */
+    lvq_bf16 *k_cache, *k_cache_lo, *v_cache, *v_cache_lo;
+} lvq_qwen2_layer;
+size_t lvq_qwen2_decode_workspace_bytes(int batch, int d, int n_heads, int n_kv_heads, int inter, int lmax, int precision);
+int lvq_qwen2_decode_step(const lvq_qwen2_layer *layers, int n_layers, float *x, int batch, int d, int n_heads, int n_kv_heads,
+                          int inter, int pos, int lmax, float rms_eps, float rope_theta, int precision, void *ws, size_t ws_bytes,
+                          lvq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,8 @@ __device__ __forceinline__ void put_out(float y, int64_t o, float *y32, uint16_t
     }
 }
 
-// one wave per row, three passes over a row that stays in L1/L2 (d <= 2048 floats = 8 KB)
+// one wave per row; rows up to 2048 floats live in registers (one pass over memory -- the three dependent passes of the first
+// version cost 12.5 us per call on a one-row decode step), longer rows re-read from L1/L2
 template <bool RMS>
 __global__ void __launch_bounds__(256) k_norm(const float *__restrict__ x, const float *__restrict__ add, int add_rows,
                                               int add_group, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -43,6 +44,40 @@ __global__ void __launch_bounds__(256) k_norm(const float *__restrict__ x, const
     if (row >= rows) return;
     const float *xr = x + row * d;
     const float *ar = add ? add + ((row / add_group) % add_rows) * (int64_t)d : nullptr;
+    const float *pr = post ? post + (row % post_rows) * (int64_t)d : nullptr;
+    if (d <= 2048) {
+        float r[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int k = lane + 64 * j;
+            r[j] = k < d ? xr[k] + (ar ? ar[k] : 0.f) : 0.f;
+        }
+        float mean = 0.f;
+        if (!RMS) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) s += r[j];                  // padding slots hold 0
+            mean = wave_sum(s) / (float)d;
+        }
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const float t = (lane + 64 * j < d) ? r[j] - mean : 0.f;
+            v += t * t;
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int k = lane + 64 * j;
+            if (k < d) {
+                const float t = (r[j] - mean) * rstd;
+                float y = RMS ? gamma[k] * t : t * gamma[k] + (beta ? beta[k] : 0.f);
+                if (pr) y += pr[k];
+                put_out(y, row * d + k, y32, y16, ylo);
+            }
+        }
+        return;
+    }
     float mean = 0.f;
     if (!RMS) {
         float s = 0.f;
@@ -55,7 +90,6 @@ __global__ void __launch_bounds__(256) k_norm(const float *__restrict__ x, const
         v += t * t;
     }
     const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
-    const float *pr = post ? post + (row % post_rows) * (int64_t)d : nullptr;
     for (int k = lane; k < d; k += 64) {
         const float t = (xr[k] + (ar ? ar[k] : 0.f) - mean) * rstd;
         float y = RMS ? gamma[k] * t : t * gamma[k] + (beta ? beta[k] : 0.f);
@@ -327,30 +361,41 @@ __global__ void __launch_bounds__(256) k_rope(uint16_t *__restrict__ xh, uint16_
     if (xl) { xl[o1] = f32_to_bf16(ra - bf16_to_f32(ha)); xl[o2] = f32_to_bf16(rb - bf16_to_f32(hb)); }
 }
 
-// one workgroup per row: (value, index) maximum with "smaller index wins" on ties
-__global__ void __launch_bounds__(256) k_argmax_rows(const float *__restrict__ x, int n, int64_t *__restrict__ out) {
-    __shared__ float sv[4];
-    __shared__ int si[4];
-    const float *row = x + (int64_t)blockIdx.x * n;
-    float bv = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float v = row[i];
-        if (v > bv || bi == 0x7fffffff) { bv = v; bi = i; }        // increasing i per thread: ">" keeps the first maximum
+// argmax over wide rows (vocabulary 151 936): one workgroup per row streamed 600 KB through one CU (191 us).  Now a row is split
+// into chunks of 8192; every workgroup reduces its chunk and publishes (orderable value bits << 32 | ~index) with one 64-bit
+// atomicMax into out[row] (zeroed first), a second tiny kernel unpacks the index.  Larger value wins; equal values: smaller index.
+constexpr int ARGMAX_CHUNK = 8192;
+__device__ __forceinline__ unsigned long long argmax_pack(float v, int i) {
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                 // monotone float -> uint
+    return ((unsigned long long)u << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+}
+__global__ void __launch_bounds__(256) k_argmax_partial(const float *__restrict__ x, int n, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long sw[4];
+    const float *row = x + (int64_t)blockIdx.y * n;
+    const int c0 = blockIdx.x * ARGMAX_CHUNK, c1 = c0 + ARGMAX_CHUNK < n ? c0 + ARGMAX_CHUNK : n;
+    unsigned long long best = 0ull;
+    for (int i = c0 + threadIdx.x; i < c1; i += 256) {
+        const unsigned long long p = argmax_pack(row[i], i);
+        best = p > best ? p : best;
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
-        const float ov = __shfl_xor(bv, o);
-        const int oi = __shfl_xor(bi, o);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        const unsigned long long q = __shfl_xor(best, o);
+        best = q > best ? q : best;
     }
-    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w)
-            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
-        out[blockIdx.x] = bi == 0x7fffffff ? 0 : bi;
+        for (int w = 1; w < 4; ++w) best = sw[w] > best ? sw[w] : best;
+        atomicMax(&out[blockIdx.y], best);
     }
+}
+__global__ void __launch_bounds__(256) k_argmax_final(unsigned long long *__restrict__ out, int64_t rows) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const unsigned long long p = out[r];
+    reinterpret_cast<int64_t *>(out)[r] = p ? (int64_t)(0xffffffffu - (uint32_t)(p & 0xffffffffull)) : 0;
 }
 
 __global__ void __launch_bounds__(256) k_swiglu(const float *__restrict__ gu, int64_t rows, int inter, uint16_t *__restrict__ oh,
@@ -495,7 +540,12 @@ extern "C" int lvq_argmax_rows(const float *x, int64_t rows, int n, int64_t *out
     if (rows < 0 || n <= 0) return LVQ_EINVAL;
     if (rows == 0) return LVQ_OK;
     if (!x || !out_idx) return LVQ_EINVAL;
-    hipLaunchKernelGGL(k_argmax_rows, dim3((unsigned)rows), dim3(256), 0, lvq_s(stream), x, n, out_idx);
+    if (rows > 65535) return LVQ_EUNSUPPORTED;
+    hipStream_t st = lvq_s(stream);
+    unsigned long long *packed = reinterpret_cast<unsigned long long *>(out_idx);
+    hipMemsetAsync(packed, 0, sizeof(unsigned long long) * rows, st);
+    hipLaunchKernelGGL(k_argmax_partial, dim3((unsigned)lvq_cdiv(n, ARGMAX_CHUNK), (unsigned)rows), dim3(256), 0, st, x, n, packed);
+    hipLaunchKernelGGL(k_argmax_final, dim3((unsigned)lvq_cdiv(rows, 256)), dim3(256), 0, st, packed, rows);
     return lvq_launch_status();
 }
 

@@ -1259,6 +1259,104 @@ __global__ void __launch_bounds__(256) k_bf16_to_f32(const uint16_t *__restrict_
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Skinny-M path (M <= 8: one decode step of the language head): C[m, n] = sum_k A[m, k] W[n, k] is a stream over W
+// (HBM-bound: 2 N K bytes for 2 M N K flops), which the 64x64 MFMA tile kernel reads with N/64 workgroups and one row-tile of
+// useful work each -- 26 us per projection of the 0.5 B decoder, 2.5 ms per token.  Here a wave owns GEMV_R rows of W, lanes split
+// K in 16-byte chunks (coalesced 1 KB per row and step), fp32 FMAs, one shuffle reduction at the end, the epilogue of the tile
+// kernels (bias, GELU, alpha, residual, row table; f32 / bf16 / bf16-lo outputs).  bf16x3: a_hi w_hi + a_hi w_lo + a_lo w_hi.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int GEMV_R = 4;
+__device__ __forceinline__ void bf8_to_f32(const uint4 v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <int MM, bool X3>
+__global__ void __launch_bounds__(256) k_gemv(const uint16_t *__restrict__ a, const uint16_t *__restrict__ a_lo, const uint16_t *__restrict__ w,
+                                              const uint16_t *__restrict__ w_lo, const float *__restrict__ bias, const float *__restrict__ residual,
+                                              const float *__restrict__ rowtab, int64_t rowtab_rows, float alpha, int gelu, int m, int n, int k,
+                                              int64_t lda, int64_t ldw, int64_t ldc, float *__restrict__ c32, uint16_t *__restrict__ c16,
+                                              uint16_t *__restrict__ c16lo) {
+    const int lane = threadIdx.x & 63;
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GEMV_R;
+    if (n0 >= n) return;
+    float acc[MM][GEMV_R];
+#pragma unroll
+    for (int mi = 0; mi < MM; ++mi)
+#pragma unroll
+        for (int r = 0; r < GEMV_R; ++r) acc[mi][r] = 0.f;
+    for (int k0 = lane * 8; k0 < k; k0 += 64 * 8) {
+        float af[MM][8], al[X3 ? MM : 1][8];
+#pragma unroll
+        for (int mi = 0; mi < MM; ++mi) {
+            const bool live = mi < m;
+            bf8_to_f32(live ? *reinterpret_cast<const uint4 *>(a + mi * lda + k0) : make_uint4(0u, 0u, 0u, 0u), af[mi]);
+            if (X3) bf8_to_f32(live ? *reinterpret_cast<const uint4 *>(a_lo + mi * lda + k0) : make_uint4(0u, 0u, 0u, 0u), al[mi]);
+        }
+#pragma unroll
+        for (int r = 0; r < GEMV_R; ++r) {
+            const int nr = n0 + r < n ? n0 + r : n - 1;            // clamp: the tail rows are computed twice, stored once
+            float wf[8], wl[8];
+            bf8_to_f32(*reinterpret_cast<const uint4 *>(w + (int64_t)nr * ldw + k0), wf);
+            if (X3) bf8_to_f32(*reinterpret_cast<const uint4 *>(w_lo + (int64_t)nr * ldw + k0), wl);
+#pragma unroll
+            for (int mi = 0; mi < MM; ++mi)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[mi][r] = fmaf(af[mi][j], wf[j], acc[mi][r]);
+                    if (X3) {
+                        acc[mi][r] = fmaf(af[mi][j], wl[j], acc[mi][r]);
+                        acc[mi][r] = fmaf(al[mi][j], wf[j], acc[mi][r]);
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MM; ++mi)
+#pragma unroll
+        for (int r = 0; r < GEMV_R; ++r) {
+            float v = acc[mi][r];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+            acc[mi][r] = v;
+        }
+    if (lane < MM * GEMV_R) {
+        const int mi = lane / GEMV_R, r = lane % GEMV_R, col = n0 + r;
+        if (mi < m && col < n) {
+            float x = 0.f;
+#pragma unroll
+            for (int a_ = 0; a_ < MM; ++a_)
+#pragma unroll
+                for (int b_ = 0; b_ < GEMV_R; ++b_)
+                    if (a_ == mi && b_ == r) x = acc[a_][b_];
+            if (bias) x += bias[col];
+            if (gelu) x = gelu_erf(x);
+            x *= alpha;
+            const int64_t o = (int64_t)mi * ldc + col;
+            if (residual) x += residual[o];
+            if (rowtab) x += rowtab[(int64_t)(mi % rowtab_rows) * n + col];
+            if (c32) c32[o] = x;
+            if (c16) {
+                const uint16_t h = f32_to_bf16(x);
+                c16[o] = h;
+                if (c16lo) c16lo[o] = f32_to_bf16(x - bf16_to_f32(h));
+            }
+        }
+    }
+}
+
+template <int MM>
+static void launch_gemv(bool x3, dim3 grid, hipStream_t st, const uint16_t *a, const uint16_t *a_lo, const uint16_t *w, const uint16_t *w_lo,
+                        const float *bias, const float *residual, const float *rowtab, int64_t rowtab_rows, float alpha, int gelu, int m, int n,
+                        int k, int64_t lda, int64_t ldw, int64_t ldc, float *c32, uint16_t *c16, uint16_t *c16lo) {
+    if (x3) hipLaunchKernelGGL((k_gemv<MM, true>), grid, dim3(256), 0, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m, n, k,
+                               lda, ldw, ldc, c32, c16, c16lo);
+    else hipLaunchKernelGGL((k_gemv<MM, false>), grid, dim3(256), 0, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m, n, k,
+                            lda, ldw, ldc, c32, c16, c16lo);
+}
+
 extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo,
                              const float *bias, const float *residual, const float *rowtab, int64_t rowtab_rows,
                              float alpha, int flags, int64_t m, int n, int k, int64_t lda, int64_t ldw, int64_t ldc,
@@ -1273,6 +1371,16 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
     if ((k & 7) || (lda & 7) || (ldw & 7) || (a_bs & 7) || (w_bs & 7) || lda < k || ldw < k || ldc < n)
         return LVQ_EUNSUPPORTED;
     if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)a_lo | (uintptr_t)w_lo) & 15) return LVQ_EUNSUPPORTED;
+    if (m <= 8 && batch == 1 && n >= 64 && getenv("LVQ_GEMM_NO_GEMV") == nullptr) {          // skinny M: stream W once (k_gemv)
+        const dim3 grid((unsigned)lvq_cdiv(n, 4 * GEMV_R));
+        const int ge_ = (flags & LVQ_GEMM_GELU) != 0;
+        hipStream_t st_ = lvq_s(stream);
+        if (m <= 1) launch_gemv<1>(a_lo != nullptr, grid, st_, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, ge_, (int)m, n, k, lda, ldw, ldc, c_f32, c_bf16, c_lo);
+        else if (m <= 2) launch_gemv<2>(a_lo != nullptr, grid, st_, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, ge_, (int)m, n, k, lda, ldw, ldc, c_f32, c_bf16, c_lo);
+        else if (m <= 4) launch_gemv<4>(a_lo != nullptr, grid, st_, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, ge_, (int)m, n, k, lda, ldw, ldc, c_f32, c_bf16, c_lo);
+        else launch_gemv<8>(a_lo != nullptr, grid, st_, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, ge_, (int)m, n, k, lda, ldw, ldc, c_f32, c_bf16, c_lo);
+        return lvq_launch_status();
+    }
     GemmArgs g;
     g.nseg = a_lo ? 3 : 1;
     g.a[0] = a; g.w[0] = w;

@@ -13,6 +13,7 @@ so a LoRA-wrapped base equals the base for an untrained-weights parity test (SUR
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -87,6 +88,15 @@ class _Model(nn.Module):
         self.embed_tokens = nn.Embedding(vocab, d)
         self.layers = nn.ModuleList([_Layer(d, dkv, inter) for _ in range(n_layers)])
         self.norm = _Weight(d)
+
+
+import ctypes as _ct
+
+
+class _Qwen2LayerPtrs(_ct.Structure):
+    """include/lvq.h: lvq_qwen2_layer (device pointers of one decoder layer)."""
+    _fields_ = [(n, _ct.c_void_p) for n in ("ln1", "ln2", "wqkv", "wqkv_lo", "bqkv", "wo", "wo_lo", "wgu", "wgu_lo", "wdown", "wdown_lo",
+                                             "k_cache", "k_cache_lo", "v_cache", "v_cache_lo")]
 
 
 class HeadOutput:
@@ -191,6 +201,25 @@ class StandInHead(_HipModule):
             loss = ops.cross_entropy(logits, shifted.reshape(-1).contiguous())
         return HeadOutput(logits.view(B, L, -1), loss)
 
+    def _native_layers(self, cache):
+        """Host array of lvq_qwen2_layer structs for lvq_qwen2_decode_step + the tensors that must stay alive behind it."""
+        keep, arr = [], (_Qwen2LayerPtrs * len(self.model.layers))()
+        p = lambda t: None if t is None else t.data_ptr()
+        for i, layer in enumerate(self.model.layers):
+            a = layer.self_attn
+            wqkv, bqkv = self._pack(("qkv", i), (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight),
+                                    (a.q_proj.bias, a.k_proj.bias, a.v_proj.bias))
+            wo = self._w(a.o_proj.weight)
+            wgu, _ = self._pack(("gu", i), (layer.mlp.gate_proj.weight, layer.mlp.up_proj.weight))
+            wd = self._w(layer.mlp.down_proj.weight)
+            ln1 = layer.input_layernorm.weight.detach().float().contiguous()
+            ln2 = layer.post_attention_layernorm.weight.detach().float().contiguous()
+            (kh, kl), (vh, vl) = cache[i]
+            keep += [wqkv, bqkv, wo, wgu, wd, ln1, ln2]
+            arr[i] = _Qwen2LayerPtrs(p(ln1), p(ln2), p(wqkv[0]), p(wqkv[1]), p(bqkv), p(wo[0]), p(wo[1]), p(wgu[0]), p(wgu[1]),
+                                     p(wd[0]), p(wd[1]), p(kh), p(kl), p(vh), p(vl))
+        return arr, keep
+
     @torch.no_grad()
     def generate(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, max_new_tokens: int = 64,
                  do_sample: bool = False, num_beams: int = 1, pad_token_id: Optional[int] = None,
@@ -215,6 +244,14 @@ class StandInHead(_HipModule):
                       torch.empty((B, lmax, dkv), dtype=torch.bfloat16, device=dev) if split else None)
         cache = [(mk(), mk()) for _ in self.model.layers]
         x = self._layers(_f32(inputs_embeds).view(B * L, d), B, L, 0, cache)          # prefill
+        native = not os.environ.get("LVQ_DECODE_PYTHON")       # decode steps: one native call per token (csrc/decoder.hip)
+        if native:
+            lib = F.lib()
+            layers_arr, keep = self._native_layers(cache)
+            prec = 3 if split else 1
+            nbytes = lib.lvq_qwen2_decode_workspace_bytes(F.cint(B), F.cint(d), F.cint(c["n_heads"]), F.cint(c["n_kv_heads"]),
+                                                          F.cint(c["inter"]), F.cint(lmax), F.cint(prec))
+            step_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
         step_logits = self._logits(x.view(B, L, d)[:, -1].contiguous())                 # [B, V]
         pad = 0 if pad_token_id is None else int(pad_token_id)
         unfinished = torch.ones(B, dtype=torch.bool, device=dev)
@@ -232,7 +269,15 @@ class StandInHead(_HipModule):
                     break
             if t + 1 == max_new_tokens:
                 break
-            x = self._layers(self.embed(nxt).float().contiguous(), B, 1, L + t, cache)
+            x = self.embed(nxt).float().contiguous()
+            if native:
+                rc = lib.lvq_qwen2_decode_step(layers_arr, F.cint(len(self.model.layers)), F.ptr(x), F.cint(B), F.cint(d),
+                                               F.cint(c["n_heads"]), F.cint(c["n_kv_heads"]), F.cint(c["inter"]), F.cint(L + t), F.cint(lmax),
+                                               F.cfloat(c["rms_eps"]), F.cfloat(c["rope_theta"]), F.cint(prec), F.ptr(step_ws),
+                                               F.csize(step_ws.numel()), F.stream_ptr(dev))
+                F.check(rc, "lvq_qwen2_decode_step")
+            else:
+                x = self._layers(x, B, 1, L + t, cache)
             step_logits = self._logits(x)
         out = torch.stack(ids, dim=1)
         return (out, torch.stack(scores, dim=1)) if output_scores else out

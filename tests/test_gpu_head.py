@@ -81,6 +81,14 @@ def test_greedy_generate_vs_transformers(prec, tol):
         full = torch.cat((inp, base.embed(ids[:, :-1])), dim=1)
         ref = base(inputs_embeds=full).logits[:, inp.shape[1] - 1:]
     assert (ref - scores).abs().max().item() < (1e-3 if prec == "bf16x3" else tol)
+    # native decode-step runtime (default) == the Python-driven loop, bit for bit
+    import os
+    os.environ["LVQ_DECODE_PYTHON"] = "1"
+    try:
+        ids_py, scores_py = base.generate(inputs_embeds=inp, attention_mask=attn, max_new_tokens=n, do_sample=False, output_scores=True)
+    finally:
+        del os.environ["LVQ_DECODE_PYTHON"]
+    assert torch.equal(ids_py, ids) and torch.equal(scores_py, scores)
     ids2 = base.generate(inputs_embeds=inp, attention_mask=attn, max_new_tokens=n, do_sample=False, pad_token_id=0,
                          eos_token_id=int(g["eos"]))
     assert np.array_equal(ids2.cpu().numpy(), g["ids_eos"])
