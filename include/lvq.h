@@ -301,6 +301,12 @@ int lvq_sparse_to_dense(const float *feats, const int32_t *indices, int index_co
  *   x [batch, d] fp32: embedding of the new token in, hidden state out (final norm + lm head are the caller's)
  *   layers: HOST array of n_layers structs of DEVICE pointers; weights are bf16 (hi) with optional lo parts (precision 3)
  *   caches [batch, lmax, dkv] bf16 (post-rotary keys); pos < lmax; precision: 1 = bf16, 3 = bf16x3 */
+/* RMSNorm fused into a skinny projection (m <= 8 rows): C = (RMSNorm(x) * gamma rounded to bf16[, lo]) @ W^T (+ bias); the
+ * rounding and summation order are lvq_rmsnorm's, so the result is bit-identical to lvq_rmsnorm + lvq_gemm_bf16. */
+int lvq_gemv_rmsnorm_bf16(const float *x, const float *gamma, float eps, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,
+                          int m, int n, int k, int64_t ldw, int64_t ldc, float *c_f32, lvq_bf16 *c_bf16, lvq_bf16 *c_lo,
+                          lvq_stream_t stream);
+
 typedef struct {
     const float *ln1, *ln2;                       /* input_layernorm / post_attention_layernorm weights [d] */
     const lvq_bf16 *wqkv, *wqkv_lo;               /* [d + 2 dkv, d]  (q_proj | k_proj | v_proj rows) */

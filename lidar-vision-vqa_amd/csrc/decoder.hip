@@ -83,9 +83,14 @@ extern "C" int lvq_qwen2_decode_step(const lvq_qwen2_layer *layers, int n_layers
     for (int l = 0; l < n_layers; ++l) {
         const lvq_qwen2_layer &L = layers[l];
         if (x3 && !(L.wqkv_lo && L.wo_lo && L.wgu_lo && L.wdown_lo && L.k_cache_lo && L.v_cache_lo)) return LVQ_EINVAL;
-        LVQ_TRY(lvq_rmsnorm(xa, L.ln1, rms_eps, batch, d, nullptr, w.h, h_lo, stream));
-        LVQ_TRY(lvq_gemm_bf16(w.h, h_lo, L.wqkv, x3 ? L.wqkv_lo : nullptr, L.bqkv, nullptr, nullptr, 0, 1.0f, 0, batch, (int)ld, d, d, d, ld, 1, 0,
-                              0, 0, nullptr, w.qkv, qkv_lo, stream));
+        if (batch <= 8) {                      // RMSNorm fused into the projection (bit-identical to the pair, one launch less)
+            LVQ_TRY(lvq_gemv_rmsnorm_bf16(xa, L.ln1, rms_eps, L.wqkv, x3 ? L.wqkv_lo : nullptr, L.bqkv, batch, (int)ld, d, d, ld, nullptr, w.qkv, qkv_lo,
+                                          stream));
+        } else {
+            LVQ_TRY(lvq_rmsnorm(xa, L.ln1, rms_eps, batch, d, nullptr, w.h, h_lo, stream));
+            LVQ_TRY(lvq_gemm_bf16(w.h, h_lo, L.wqkv, x3 ? L.wqkv_lo : nullptr, L.bqkv, nullptr, nullptr, 0, 1.0f, 0, batch, (int)ld, d, d, d, ld, 1, 0,
+                                  0, 0, nullptr, w.qkv, qkv_lo, stream));
+        }
         // q heads and k heads are adjacent columns of the packed row: one rotary launch covers both
         LVQ_TRY(lvq_rope_inplace_at(w.qkv, qkv_lo, batch, 1, pos, n_heads + n_kv_heads, dh, ld, rope_theta, stream));
         hipLaunchKernelGGL(k_cache_append, dim3((unsigned)lvq_cdiv((int64_t)batch * dkv, 256)), dim3(256), 0, st, w.qkv, qkv_lo, batch, d, dkv, pos,
@@ -95,9 +100,14 @@ extern "C" int lvq_qwen2_decode_step(const lvq_qwen2_layer *layers, int n_layers
                                    d, d, dh, scale, 0, w.o, o_lo, w.attn, w.attn_bytes, stream));
         LVQ_TRY(lvq_gemm_bf16(w.o, o_lo, L.wo, x3 ? L.wo_lo : nullptr, nullptr, xa, nullptr, 0, 1.0f, 0, batch, d, d, d, d, d, 1, 0, 0, 0, xb,
                               nullptr, nullptr, stream));
-        LVQ_TRY(lvq_rmsnorm(xb, L.ln2, rms_eps, batch, d, nullptr, w.h, h_lo, stream));
-        LVQ_TRY(lvq_gemm_bf16(w.h, h_lo, L.wgu, x3 ? L.wgu_lo : nullptr, nullptr, nullptr, nullptr, 0, 1.0f, 0, batch, 2 * inter, d, d, d,
-                              2 * (int64_t)inter, 1, 0, 0, 0, w.gu, nullptr, nullptr, stream));
+        if (batch <= 8) {
+            LVQ_TRY(lvq_gemv_rmsnorm_bf16(xb, L.ln2, rms_eps, L.wgu, x3 ? L.wgu_lo : nullptr, nullptr, batch, 2 * inter, d, d, 2 * (int64_t)inter, w.gu,
+                                          nullptr, nullptr, stream));
+        } else {
+            LVQ_TRY(lvq_rmsnorm(xb, L.ln2, rms_eps, batch, d, nullptr, w.h, h_lo, stream));
+            LVQ_TRY(lvq_gemm_bf16(w.h, h_lo, L.wgu, x3 ? L.wgu_lo : nullptr, nullptr, nullptr, nullptr, 0, 1.0f, 0, batch, 2 * inter, d, d, d,
+                                  2 * (int64_t)inter, 1, 0, 0, 0, w.gu, nullptr, nullptr, stream));
+        }
         LVQ_TRY(lvq_swiglu(w.gu, batch, inter, w.act, act_lo, stream));
         LVQ_TRY(lvq_gemm_bf16(w.act, act_lo, L.wdown, x3 ? L.wdown_lo : nullptr, nullptr, xb, nullptr, 0, 1.0f, 0, batch, d, inter, inter, inter, d,
                               1, 0, 0, 0, xa, nullptr, nullptr, stream));

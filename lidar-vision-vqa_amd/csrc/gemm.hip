@@ -1266,22 +1266,41 @@ __global__ void __launch_bounds__(256) k_bf16_to_f32(const uint16_t *__restrict_
 // K in 16-byte chunks (coalesced 1 KB per row and step), fp32 FMAs, one shuffle reduction at the end, the epilogue of the tile
 // kernels (bias, GELU, alpha, residual, row table; f32 / bf16 / bf16-lo outputs).  bf16x3: a_hi w_hi + a_hi w_lo + a_lo w_hi.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int GEMV_R = 4;
 __device__ __forceinline__ void bf8_to_f32(const uint4 v, float (&f)[8]) {
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
     f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
     f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
     f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
-template <int MM, bool X3>
+// NORM: A is not read as bf16 but produced on the fly as RMSNorm(xf) * gamma rounded to bf16 (hi[, lo]) -- exactly what lvq_rmsnorm
+// writes (same per-lane summation order, same expression), so the result is bit-identical to the rmsnorm + GEMV pair while two of
+// the ~12 launches of a decoder layer disappear (a one-row norm kernel costs 12.8 us of dependent latency, 0.63 ms per token).
+template <int MM, bool X3, int GEMV_R, bool NORM>
 __global__ void __launch_bounds__(256) k_gemv(const uint16_t *__restrict__ a, const uint16_t *__restrict__ a_lo, const uint16_t *__restrict__ w,
                                               const uint16_t *__restrict__ w_lo, const float *__restrict__ bias, const float *__restrict__ residual,
                                               const float *__restrict__ rowtab, int64_t rowtab_rows, float alpha, int gelu, int m, int n, int k,
                                               int64_t lda, int64_t ldw, int64_t ldc, float *__restrict__ c32, uint16_t *__restrict__ c16,
-                                              uint16_t *__restrict__ c16lo) {
+                                              uint16_t *__restrict__ c16lo, const float *__restrict__ xf, const float *__restrict__ gamma,
+                                              float eps) {
     const int lane = threadIdx.x & 63;
     const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GEMV_R;
     if (n0 >= n) return;
+    float rstd[MM];
+    if (NORM) {
+        // lvq_rmsnorm's statistics: lane-strided sum of squares (k = lane, lane + 64, ...), butterfly wave sum, IEEE 1/sqrt
+#pragma unroll
+        for (int mi = 0; mi < MM; ++mi) {
+            float v = 0.f;
+            if (mi < m)
+                for (int kk = lane; kk < k; kk += 64) {
+                    const float t = xf[(int64_t)mi * k + kk];
+                    v += t * t;
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            rstd[mi] = 1.0f / sqrtf(v / (float)k + eps);
+        }
+    }
     float acc[MM][GEMV_R];
 #pragma unroll
     for (int mi = 0; mi < MM; ++mi)
@@ -1292,8 +1311,23 @@ __global__ void __launch_bounds__(256) k_gemv(const uint16_t *__restrict__ a, co
 #pragma unroll
         for (int mi = 0; mi < MM; ++mi) {
             const bool live = mi < m;
-            bf8_to_f32(live ? *reinterpret_cast<const uint4 *>(a + mi * lda + k0) : make_uint4(0u, 0u, 0u, 0u), af[mi]);
-            if (X3) bf8_to_f32(live ? *reinterpret_cast<const uint4 *>(a_lo + mi * lda + k0) : make_uint4(0u, 0u, 0u, 0u), al[mi]);
+            if (NORM) {
+                const float4 x0 = live ? *reinterpret_cast<const float4 *>(xf + (int64_t)mi * k + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 x1 = live ? *reinterpret_cast<const float4 *>(xf + (int64_t)mi * k + k0 + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 g0 = *reinterpret_cast<const float4 *>(gamma + k0), g1 = *reinterpret_cast<const float4 *>(gamma + k0 + 4);
+                const float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                const float gs[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = gs[j] * ((xs[j] - 0.f) * rstd[mi]);          // k_norm<true>: gamma[k] * ((x - mean) * rstd), mean = 0
+                    const uint16_t h = f32_to_bf16(y);
+                    af[mi][j] = bf16_to_f32(h);
+                    if (X3) al[mi][j] = bf16_to_f32(f32_to_bf16(y - bf16_to_f32(h)));
+                }
+            } else {
+                bf8_to_f32(live ? *reinterpret_cast<const uint4 *>(a + mi * lda + k0) : make_uint4(0u, 0u, 0u, 0u), af[mi]);
+                if (X3) bf8_to_f32(live ? *reinterpret_cast<const uint4 *>(a_lo + mi * lda + k0) : make_uint4(0u, 0u, 0u, 0u), al[mi]);
+            }
         }
 #pragma unroll
         for (int r = 0; r < GEMV_R; ++r) {
@@ -1347,14 +1381,43 @@ __global__ void __launch_bounds__(256) k_gemv(const uint16_t *__restrict__ a, co
     }
 }
 
-template <int MM>
-static void launch_gemv(bool x3, dim3 grid, hipStream_t st, const uint16_t *a, const uint16_t *a_lo, const uint16_t *w, const uint16_t *w_lo,
+template <int MM, int R, bool NORM>
+static void launch_gemv_r(bool x3, hipStream_t st, const uint16_t *a, const uint16_t *a_lo, const uint16_t *w, const uint16_t *w_lo,
+                          const float *bias, const float *residual, const float *rowtab, int64_t rowtab_rows, float alpha, int gelu, int m, int n,
+                          int k, int64_t lda, int64_t ldw, int64_t ldc, float *c32, uint16_t *c16, uint16_t *c16lo, const float *xf,
+                          const float *gamma, float eps) {
+    const dim3 grid((unsigned)lvq_cdiv(n, 4 * R));
+    if (x3) hipLaunchKernelGGL((k_gemv<MM, true, R, NORM>), grid, dim3(256), 0, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m,
+                               n, k, lda, ldw, ldc, c32, c16, c16lo, xf, gamma, eps);
+    else hipLaunchKernelGGL((k_gemv<MM, false, R, NORM>), grid, dim3(256), 0, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m,
+                            n, k, lda, ldw, ldc, c32, c16, c16lo, xf, gamma, eps);
+}
+// rows of W per wave: 4 when N alone fills the chip (A reuse), 1 for narrow outputs (896-wide o_proj / down_proj: 224 waves of
+// 4 rows left 3/4 of the SIMDs idle, 9.2 us; one row per wave spreads the same stream over 896 waves)
+template <bool NORM>
+static void launch_gemv(bool x3, hipStream_t st, const uint16_t *a, const uint16_t *a_lo, const uint16_t *w, const uint16_t *w_lo,
                         const float *bias, const float *residual, const float *rowtab, int64_t rowtab_rows, float alpha, int gelu, int m, int n,
-                        int k, int64_t lda, int64_t ldw, int64_t ldc, float *c32, uint16_t *c16, uint16_t *c16lo) {
-    if (x3) hipLaunchKernelGGL((k_gemv<MM, true>), grid, dim3(256), 0, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m, n, k,
-                               lda, ldw, ldc, c32, c16, c16lo);
-    else hipLaunchKernelGGL((k_gemv<MM, false>), grid, dim3(256), 0, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m, n, k,
-                            lda, ldw, ldc, c32, c16, c16lo);
+                        int k, int64_t lda, int64_t ldw, int64_t ldc, float *c32, uint16_t *c16, uint16_t *c16lo, const float *xf,
+                        const float *gamma, float eps) {
+#define LVQ_GV(MM, R) launch_gemv_r<MM, R, NORM>(x3, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m, n, k, lda, ldw, ldc, c32, c16, c16lo, xf, gamma, eps)
+    const bool wide = n >= 4096;
+    if (m <= 1) { if (wide) LVQ_GV(1, 4); else LVQ_GV(1, 1); }
+    else if (m <= 2) { if (wide) LVQ_GV(2, 4); else LVQ_GV(2, 1); }
+    else if (m <= 4) { if (wide) LVQ_GV(4, 4); else LVQ_GV(4, 1); }
+    else { if (wide) LVQ_GV(8, 4); else LVQ_GV(8, 1); }
+#undef LVQ_GV
+}
+
+// RMSNorm fused into the skinny-M projection (decode step): C = epi(RMSNorm(x) * gamma @ W^T), x [m, k] fp32, m <= 8.
+extern "C" int lvq_gemv_rmsnorm_bf16(const float *x, const float *gamma, float eps, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,
+                                     int m, int n, int k, int64_t ldw, int64_t ldc, float *c_f32, lvq_bf16 *c_bf16, lvq_bf16 *c_lo,
+                                     lvq_stream_t stream) {
+    if (m <= 0 || m > 8 || n <= 0 || k <= 0 || !x || !gamma || !w || (!c_f32 && !c_bf16) || (c_lo && !c_bf16)) return LVQ_EINVAL;
+    if ((k & 7) || (ldw & 7) || ldw < k || ldc < n) return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)w | (uintptr_t)w_lo) & 15) return LVQ_EUNSUPPORTED;
+    launch_gemv<true>(w_lo != nullptr, lvq_s(stream), nullptr, nullptr, w, w_lo, bias, nullptr, nullptr, 1, 1.0f, 0, m, n, k, k, ldw, ldc, c_f32, c_bf16,
+                      c_lo, x, gamma, eps);
+    return lvq_launch_status();
 }
 
 extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo,
@@ -1372,13 +1435,8 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
         return LVQ_EUNSUPPORTED;
     if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)a_lo | (uintptr_t)w_lo) & 15) return LVQ_EUNSUPPORTED;
     if (m <= 8 && batch == 1 && n >= 64 && getenv("LVQ_GEMM_NO_GEMV") == nullptr) {          // skinny M: stream W once (k_gemv)
-        const dim3 grid((unsigned)lvq_cdiv(n, 4 * GEMV_R));
-        const int ge_ = (flags & LVQ_GEMM_GELU) != 0;
-        hipStream_t st_ = lvq_s(stream);
-        if (m <= 1) launch_gemv<1>(a_lo != nullptr, grid, st_, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, ge_, (int)m, n, k, lda, ldw, ldc, c_f32, c_bf16, c_lo);
-        else if (m <= 2) launch_gemv<2>(a_lo != nullptr, grid, st_, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, ge_, (int)m, n, k, lda, ldw, ldc, c_f32, c_bf16, c_lo);
-        else if (m <= 4) launch_gemv<4>(a_lo != nullptr, grid, st_, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, ge_, (int)m, n, k, lda, ldw, ldc, c_f32, c_bf16, c_lo);
-        else launch_gemv<8>(a_lo != nullptr, grid, st_, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, ge_, (int)m, n, k, lda, ldw, ldc, c_f32, c_bf16, c_lo);
+        launch_gemv<false>(a_lo != nullptr, lvq_s(stream), a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, (flags & LVQ_GEMM_GELU) != 0,
+                           (int)m, n, k, lda, ldw, ldc, c_f32, c_bf16, c_lo, nullptr, nullptr, 0.f);
         return lvq_launch_status();
     }
     GemmArgs g;
