@@ -1275,7 +1275,7 @@ __device__ __forceinline__ void bf8_to_f32(const uint4 v, float (&f)[8]) {
 // NORM: A is not read as bf16 but produced on the fly as RMSNorm(xf) * gamma rounded to bf16 (hi[, lo]) -- exactly what lvq_rmsnorm
 // writes (same per-lane summation order, same expression), so the result is bit-identical to the rmsnorm + GEMV pair while two of
 // the ~12 launches of a decoder layer disappear (a one-row norm kernel costs 12.8 us of dependent latency, 0.63 ms per token).
-template <int MM, bool X3, int GEMV_R, bool NORM>
+template <int MM, bool X3, int GEMV_R, int PRO>
 __global__ void __launch_bounds__(256) k_gemv(const uint16_t *__restrict__ a, const uint16_t *__restrict__ a_lo, const uint16_t *__restrict__ w,
                                               const uint16_t *__restrict__ w_lo, const float *__restrict__ bias, const float *__restrict__ residual,
                                               const float *__restrict__ rowtab, int64_t rowtab_rows, float alpha, int gelu, int m, int n, int k,
@@ -1285,6 +1285,7 @@ __global__ void __launch_bounds__(256) k_gemv(const uint16_t *__restrict__ a, co
     const int lane = threadIdx.x & 63;
     const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * GEMV_R;
     if (n0 >= n) return;
+    constexpr bool NORM = PRO == 1;
     float rstd[MM];
     if (NORM) {
         // lvq_rmsnorm's statistics: lane-strided sum of squares (k = lane, lane + 64, ...), butterfly wave sum, IEEE 1/sqrt
@@ -1381,25 +1382,25 @@ __global__ void __launch_bounds__(256) k_gemv(const uint16_t *__restrict__ a, co
     }
 }
 
-template <int MM, int R, bool NORM>
+template <int MM, int R, int PRO>
 static void launch_gemv_r(bool x3, hipStream_t st, const uint16_t *a, const uint16_t *a_lo, const uint16_t *w, const uint16_t *w_lo,
                           const float *bias, const float *residual, const float *rowtab, int64_t rowtab_rows, float alpha, int gelu, int m, int n,
                           int k, int64_t lda, int64_t ldw, int64_t ldc, float *c32, uint16_t *c16, uint16_t *c16lo, const float *xf,
                           const float *gamma, float eps) {
     const dim3 grid((unsigned)lvq_cdiv(n, 4 * R));
-    if (x3) hipLaunchKernelGGL((k_gemv<MM, true, R, NORM>), grid, dim3(256), 0, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m,
+    if (x3) hipLaunchKernelGGL((k_gemv<MM, true, R, PRO>), grid, dim3(256), 0, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m,
                                n, k, lda, ldw, ldc, c32, c16, c16lo, xf, gamma, eps);
-    else hipLaunchKernelGGL((k_gemv<MM, false, R, NORM>), grid, dim3(256), 0, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m,
+    else hipLaunchKernelGGL((k_gemv<MM, false, R, PRO>), grid, dim3(256), 0, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m,
                             n, k, lda, ldw, ldc, c32, c16, c16lo, xf, gamma, eps);
 }
 // rows of W per wave: 4 when N alone fills the chip (A reuse), 1 for narrow outputs (896-wide o_proj / down_proj: 224 waves of
 // 4 rows left 3/4 of the SIMDs idle, 9.2 us; one row per wave spreads the same stream over 896 waves)
-template <bool NORM>
+template <int PRO>
 static void launch_gemv(bool x3, hipStream_t st, const uint16_t *a, const uint16_t *a_lo, const uint16_t *w, const uint16_t *w_lo,
                         const float *bias, const float *residual, const float *rowtab, int64_t rowtab_rows, float alpha, int gelu, int m, int n,
                         int k, int64_t lda, int64_t ldw, int64_t ldc, float *c32, uint16_t *c16, uint16_t *c16lo, const float *xf,
                         const float *gamma, float eps) {
-#define LVQ_GV(MM, R) launch_gemv_r<MM, R, NORM>(x3, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m, n, k, lda, ldw, ldc, c32, c16, c16lo, xf, gamma, eps)
+#define LVQ_GV(MM, R) launch_gemv_r<MM, R, PRO>(x3, st, a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, gelu, m, n, k, lda, ldw, ldc, c32, c16, c16lo, xf, gamma, eps)
     const bool wide = n >= 4096;
     if (m <= 1) { if (wide) LVQ_GV(1, 4); else LVQ_GV(1, 1); }
     else if (m <= 2) { if (wide) LVQ_GV(2, 4); else LVQ_GV(2, 1); }
@@ -1415,7 +1416,7 @@ extern "C" int lvq_gemv_rmsnorm_bf16(const float *x, const float *gamma, float e
     if (m <= 0 || m > 8 || n <= 0 || k <= 0 || !x || !gamma || !w || (!c_f32 && !c_bf16) || (c_lo && !c_bf16)) return LVQ_EINVAL;
     if ((k & 7) || (ldw & 7) || ldw < k || ldc < n) return LVQ_EUNSUPPORTED;
     if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)w | (uintptr_t)w_lo) & 15) return LVQ_EUNSUPPORTED;
-    launch_gemv<true>(w_lo != nullptr, lvq_s(stream), nullptr, nullptr, w, w_lo, bias, nullptr, nullptr, 1, 1.0f, 0, m, n, k, k, ldw, ldc, c_f32, c_bf16,
+    launch_gemv<1>(w_lo != nullptr, lvq_s(stream), nullptr, nullptr, w, w_lo, bias, nullptr, nullptr, 1, 1.0f, 0, m, n, k, k, ldw, ldc, c_f32, c_bf16,
                       c_lo, x, gamma, eps);
     return lvq_launch_status();
 }
@@ -1435,7 +1436,7 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
         return LVQ_EUNSUPPORTED;
     if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)a_lo | (uintptr_t)w_lo) & 15) return LVQ_EUNSUPPORTED;
     if (m <= 8 && batch == 1 && n >= 64 && getenv("LVQ_GEMM_NO_GEMV") == nullptr) {          // skinny M: stream W once (k_gemv)
-        launch_gemv<false>(a_lo != nullptr, lvq_s(stream), a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, (flags & LVQ_GEMM_GELU) != 0,
+        launch_gemv<0>(a_lo != nullptr, lvq_s(stream), a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, (flags & LVQ_GEMM_GELU) != 0,
                            (int)m, n, k, lda, ldw, ldc, c_f32, c_bf16, c_lo, nullptr, nullptr, 0.f);
         return lvq_launch_status();
     }

@@ -137,3 +137,26 @@ def test_inference_engine_vs_unmodified_reference(prec, tmp_path):
     a = eng.generate_batch([question, question], [str(p), bev.astype(np.float16)], max_new_tokens=4, do_sample=False)
     assert len(a) == 2 and a[0] == a[1] and len(a[0]) == 4
     assert int(g["l_reference_answer_is_empty"]) == 1
+
+
+@pytest.mark.parametrize("dh,nkv,H,Hk", [(64, 300, 4, 2), (64, 1, 2, 2), (128, 1237, 6, 2), (64, 4099, 14, 2)])
+@pytest.mark.parametrize("split", [False, True])
+def test_decode_attention_one_query(dh, nkv, H, Hk, split):
+    """lvq_attention_bf16 with one query per sequence (the decode-step kernel, head_dim 64 / 128, grouped KV heads, strided cache
+    layout) against softmax(q k^T / sqrt(dh)) v in fp32 on the operands the kernel sees."""
+    from lidar_vision_vqa_amd import ops
+    B, lmax = 2, nkv + 5
+    g = torch.Generator().manual_seed(dh * 1000 + nkv)
+    q = torch.randn(B, H * dh, generator=g)
+    kc = torch.randn(B, lmax, Hk * dh, generator=g)
+    vc = torch.randn(B, lmax, Hk * dh, generator=g)
+    rnd = (lambda t: t) if split else (lambda t: t.to(torch.bfloat16).float())
+    qd, kd, vd = (ops.cast(t.reshape(-1, t.shape[-1]).contiguous().to(DEV), split) for t in (q, kc, vc))
+    out = ops.attention(qd, kd, vd, batch=B, n_heads=H, n_kv_heads=Hk, nq=1, nkv=nkv, dh=dh, q_strides=(H * dh, H * dh, dh),
+                        k_strides=(lmax * Hk * dh, Hk * dh, dh), v_strides=(lmax * Hk * dh, Hk * dh, dh), scale=1.0 / dh ** 0.5)
+    got = out[0].float() + (out[1].float() if split else 0)
+    qq = rnd(q).view(B, H, 1, dh)
+    kk = rnd(kc)[:, :nkv].view(B, nkv, Hk, dh).permute(0, 2, 1, 3).repeat_interleave(H // Hk, dim=1)
+    vv = rnd(vc)[:, :nkv].view(B, nkv, Hk, dh).permute(0, 2, 1, 3).repeat_interleave(H // Hk, dim=1)
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2) / dh ** 0.5, dim=-1) @ vv).reshape(B, H * dh)
+    assert (got.cpu() - ref).abs().max().item() < (2e-5 if split else 8e-3)
