@@ -160,3 +160,40 @@ def test_decode_attention_one_query(dh, nkv, H, Hk, split):
     vv = rnd(vc)[:, :nkv].view(B, nkv, Hk, dh).permute(0, 2, 1, 3).repeat_interleave(H // Hk, dim=1)
     ref = (torch.softmax(qq @ kk.transpose(-1, -2) / dh ** 0.5, dim=-1) @ vv).reshape(B, H * dh)
     assert (got.cpu() - ref).abs().max().item() < (2e-5 if split else 8e-3)
+
+
+@pytest.mark.parametrize("m,n,k", [(1, 896, 896), (2, 1152, 128), (3, 100, 64), (5, 4864, 896), (8, 9728, 256), (7, 65, 4864)])
+@pytest.mark.parametrize("split", [False, True])
+def test_skinny_gemv_matches_tile_gemm(m, n, k, split, monkeypatch):
+    """lvq_gemm_bf16 with M <= 8 (k_gemv: one pass over W, fp32 FMAs) against the MFMA tile kernels on the same operands: every
+    epilogue option (bias, GELU, alpha, residual, row table; fp32 and bf16 / lo outputs), narrow and wide N (1 or 4 rows per wave),
+    N not a multiple of the rows per wave."""
+    from lidar_vision_vqa_amd import ops, _ffi as F
+    import ctypes
+    g = torch.Generator().manual_seed(m * 100000 + n + k)
+    a = ops.cast((torch.randn(m, k, generator=g)).to(DEV), split)
+    w = ops.cast((torch.randn(n, k, generator=g) * 0.1).to(DEV), split)
+    bias = torch.randn(n, generator=g).to(DEV)
+    res = torch.randn(m, n, generator=g).to(DEV)
+    tab = torch.randn(3, n, generator=g).to(DEV)
+
+    def run(gelu, alpha, use_res, use_tab):
+        c32 = torch.empty((m, n), dtype=torch.float32, device=DEV)
+        ch = torch.empty((m, n), dtype=torch.bfloat16, device=DEV)
+        cl = torch.empty((m, n), dtype=torch.bfloat16, device=DEV) if split else None
+        rc = F.lib().lvq_gemm_bf16(F.ptr(a[0]), F.ptr(a[1]), F.ptr(w[0]), F.ptr(w[1]), F.ptr(bias), F.ptr(res if use_res else None),
+                                   F.ptr(tab if use_tab else None), F.i64(3 if use_tab else 0), F.cfloat(alpha), F.cint(1 if gelu else 0),
+                                   F.i64(m), F.cint(n), F.cint(k), F.i64(k), F.i64(k), F.i64(n), F.cint(1), F.i64(0), F.i64(0), F.i64(0),
+                                   F.ptr(c32), F.ptr(ch), F.ptr(cl), F.stream_ptr(torch.device(DEV)))
+        F.check(rc, "lvq_gemm_bf16")
+        torch.cuda.synchronize()
+        return c32.cpu(), ch.float().cpu() + (cl.float().cpu() if split else 0)
+
+    for gelu, alpha, use_res, use_tab in [(False, 1.0, False, False), (True, 0.5, True, True), (False, 2.0, True, False)]:
+        got32, got16 = run(gelu, alpha, use_res, use_tab)
+        monkeypatch.setenv("LVQ_GEMM_NO_GEMV", "1")
+        ref32, ref16 = run(gelu, alpha, use_res, use_tab)
+        monkeypatch.delenv("LVQ_GEMM_NO_GEMV")
+        scale = float(ref32.abs().max()) + 1e-6
+        assert (got32 - ref32).abs().max().item() < 2e-5 * scale * max(1.0, k / 256)        # same products, different summation order
+        assert (got16 - ref16).abs().max().item() < (2e-5 if split else 8e-3) * scale
