@@ -963,7 +963,10 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, 
     // enough workgroups for >= ~5 dispatch rounds (3 resident workgroups per CU): with ~1.1 rounds the straggler round
     // doubled the kernel time (4 ms vs 8 ms run to run)
     int ns = (int)((4096 + base - 1) / base);
-    if (ns > n_tiles / 8) ns = n_tiles / 8;            // at least 8 KV tiles per split
+    // at least 8 KV tiles per split -- 3 for a decode step (a handful of queries: B*H workgroups walking ~14 tiles each in series
+    // took 17 us per layer at 1 x 870 keys; 4 splits + combine: 1.39 -> 1.22 ms per token of the 24-layer decoder)
+    const int min_tiles = (p.nqt == 1 && nq <= 16) ? 3 : 8;
+    if (ns > n_tiles / min_tiles) ns = n_tiles / min_tiles;
     // head_dim 96 / 128: a partial is (dh + 2) fp32 per query and split -- with the 5-round rule the partials of the reference's
     // own VATLiDAR geometry (576 x 32 400, head_dim 112, 8 heads: 63 splits) were 132 MB against 116 MB of K|V.  One full
     // round of workgroups is enough there (measured: 63 splits 0.481 ms, 32: 0.416, 19: 0.395, 12: 0.392, 8: 0.466 for the

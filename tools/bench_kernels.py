@@ -212,7 +212,7 @@ def bench_decode():
         t_all = time.perf_counter() - t0
         per = (t_all - t_pre) / (n_new - 1)
         print(f"decode {prec}: prefill L={L}: {t_pre * 1e3:.1f} ms; {per * 1e3:.2f} ms/token ({1 / per:.0f} tokens/s, B={B}; "
-              f"one native call per token, 24 layers x 8 dependent launches)")
+              f"one native call per token, 24 layers x 9 dependent launches)")
 
 
 def bench_attn_one():
