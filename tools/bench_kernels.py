@@ -193,26 +193,27 @@ def bench_decode():
     """SURVEY 8f f4 at the reference's true decoder size (Qwen2.5-0.5B geometry, random weights): prefill of the multimodal prompt
     (2 + 576 + 2 + 258 + 32 prompt positions) and greedy decode steps with the KV cache."""
     from lidar_vision_vqa_amd import head
-    B, L, n_new = 1, 870, 32
+    L, n_new = 870, 32
     base = head.StandInHead(151936, 896, 4864, 14, 2, 24, 1e-6, 1000000.0).to(DEV).eval()
     for p in base.parameters():
         p.data.normal_(0, 0.02)
-    for prec in ("bf16", "bf16x3"):
-        base.precision = prec
-        inp = torch.randn(B, L, 896, device=DEV) * 0.05
-        base.generate(inputs_embeds=inp, max_new_tokens=4)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        base.generate(inputs_embeds=inp, max_new_tokens=1)
-        torch.cuda.synchronize()
-        t_pre = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        base.generate(inputs_embeds=inp, max_new_tokens=n_new)
-        torch.cuda.synchronize()
-        t_all = time.perf_counter() - t0
-        per = (t_all - t_pre) / (n_new - 1)
-        print(f"decode {prec}: prefill L={L}: {t_pre * 1e3:.1f} ms; {per * 1e3:.2f} ms/token ({1 / per:.0f} tokens/s, B={B}; "
-              f"one native call per token, 24 layers x 9 dependent launches)")
+    for B in (1, 8):
+        for prec in ("bf16", "bf16x3"):
+            base.precision = prec
+            inp = torch.randn(B, L, 896, device=DEV) * 0.05
+            base.generate(inputs_embeds=inp, max_new_tokens=4)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            base.generate(inputs_embeds=inp, max_new_tokens=1)
+            torch.cuda.synchronize()
+            t_pre = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            base.generate(inputs_embeds=inp, max_new_tokens=n_new)
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+            per = (t_all - t_pre) / (n_new - 1)
+            print(f"decode {prec}: B={B} prefill L={L}: {t_pre * 1e3:.1f} ms; {per * 1e3:.2f} ms/step ({B / per:.0f} tokens/s; "
+                  f"one native call per step, 24 layers x 9 dependent launches)")
 
 
 def bench_attn_one():
