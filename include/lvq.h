@@ -271,7 +271,8 @@ int lvq_f16_to_f32(const uint16_t *src, float *dst, int64_t n, lvq_stream_t stre
  *   features_unique = zeros(len(indices_unique), C).index_add_(0, inv, features)
  * indices_bzyx [m,4] int32 (b, z, y, x), feats [m,c] fp32, grid (ny, nx) = spatial_shape[1:].
  *   out_indices_byx [cap,3] int32: unique (b, y, x) rows in ascending lexicographic order (= torch.unique(dim=0))
- *   out_feats [cap,c] fp32: MUST BE ZERO ON ENTRY; sums (fp32 atomics, order unspecified as in the CUDA index_add_)
+ *   out_feats [cap,c] fp32: rows [0, counts[0]) are written; every row is the sum of its contributors in ascending input-row
+ *   order (the order of the CPU index_add_: deterministic, bit-identical to it; the CUDA index_add_ of the reference is atomic)
  *   unq_inv [m] int32: row of out_* each input row was added to;  counts [2] int32: counts[0] = number of unique rows
  *   cap >= min(m, batch*ny*nx).  batch*ny*nx must stay below 2^31 (LVQ_EOVERFLOW). */
 size_t lvq_sparse_bev_merge_workspace_bytes(int64_t m, int batch, int ny, int nx);

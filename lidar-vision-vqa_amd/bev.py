@@ -147,7 +147,7 @@ def bev_out(x_conv: SparseTensor) -> SparseTensor:
     ws = workspace(nbytes, dev, "bevmerge")
     cap = max(1, min(m, x_conv.batch_size * ny * nx))
     out_idx = torch.empty((cap, 3), dtype=torch.int32, device=dev)
-    out_feats = torch.zeros((cap, c), dtype=torch.float32, device=dev)
+    out_feats = torch.empty((cap, c), dtype=torch.float32, device=dev)
     inv = torch.empty((max(m, 1),), dtype=torch.int32, device=dev)
     counts = torch.zeros((2,), dtype=torch.int32, device=dev)
     rc = L.lvq_sparse_bev_merge(F.ptr(idx), F.ptr(feats), F.i64(m), F.cint(c), F.cint(x_conv.batch_size), F.cint(ny), F.cint(nx),
