@@ -73,40 +73,33 @@ class InferenceEngine:
 
     @torch.no_grad()
     def build_inputs_embeds(self, prompt: str, lidar_prompts: torch.Tensor, vision_prompts: Optional[torch.Tensor] = None) -> tuple:
-        """Interleave text embeddings and the scaled modal prompts between their start / end tokens
-        (inference_engine.py:139-227).  The pieces are row gathers, a scale and a concatenation."""
-        enc = self.tokenizer(prompt, return_tensors="pt", add_special_tokens=False)
-        input_ids = enc["input_ids"].to(self.device)
-        text_embeds = self.base_model.get_input_embeddings()(input_ids)
-        ids_flat = input_ids[0]
-        embeds_list = []
-        pos = 0
+        """Text embeddings with the scaled modal prompts spliced in between their marker tokens (inference_engine.py:139-227):
+        for vision (when enabled and given) and then LiDAR, the first <x_start> / <x_end> pair found in the prompt ids is
+        replaced by  E(<x_start>), prompts * prefix_scale, E(<x_end>);  text in front of, between and behind the pairs is kept.
+        The pieces are row gathers, a scale and a concatenation.  Returns (inputs_embeds [1, L, d], all-ones mask [1, L])."""
+        ids = self.tokenizer(prompt, return_tensors="pt", add_special_tokens=False)["input_ids"].to(self.device)
+        text = self.base_model.get_input_embeddings()(ids)                  # [1, n_text, d]
+        row = ids[0]
+        modal = []
         if self.use_vision and vision_prompts is not None:
-            vs_pos = (ids_flat == self.vision_start_id).nonzero(as_tuple=True)[0]
-            ve_pos = (ids_flat == self.vision_end_id).nonzero(as_tuple=True)[0]
-            if len(vs_pos) > 0 and len(ve_pos) > 0:
-                vs, ve = vs_pos[0].item(), ve_pos[0].item()
-                if vs > pos:
-                    embeds_list.append(text_embeds[:, pos:vs, :])
-                embeds_list.append(text_embeds[:, vs:vs + 1, :])
-                embeds_list.append(vision_prompts * self.prefix_scale)
-                embeds_list.append(text_embeds[:, ve:ve + 1, :])
-                pos = ve + 1
-        ls_pos = (ids_flat == self.lidar_start_id).nonzero(as_tuple=True)[0]
-        le_pos = (ids_flat == self.lidar_end_id).nonzero(as_tuple=True)[0]
-        if len(ls_pos) > 0 and len(le_pos) > 0:
-            ls, le = ls_pos[0].item(), le_pos[0].item()
-            if ls > pos:
-                embeds_list.append(text_embeds[:, pos:ls, :])
-            embeds_list.append(text_embeds[:, ls:ls + 1, :])
-            embeds_list.append(lidar_prompts * self.prefix_scale)
-            embeds_list.append(text_embeds[:, le:le + 1, :])
-            pos = le + 1
-        if pos < text_embeds.shape[1]:
-            embeds_list.append(text_embeds[:, pos:, :])
-        inputs_embeds = torch.cat(embeds_list, dim=1)
-        attention_mask = torch.ones(1, inputs_embeds.shape[1], dtype=torch.long, device=self.device)
-        return inputs_embeds, attention_mask
+            modal.append((self.vision_start_id, self.vision_end_id, vision_prompts))
+        modal.append((self.lidar_start_id, self.lidar_end_id, lidar_prompts))
+        chunks, cursor = [], 0
+        for start_id, end_id, prompts in modal:
+            starts = torch.nonzero(row == start_id).flatten()
+            ends = torch.nonzero(row == end_id).flatten()
+            if starts.numel() == 0 or ends.numel() == 0:
+                continue                                                     # marker pair absent: this modality is not spliced
+            s0, e0 = int(starts[0]), int(ends[0])
+            if s0 > cursor:
+                chunks.append(text[:, cursor:s0])
+            chunks += [text[:, s0:s0 + 1], prompts * self.prefix_scale, text[:, e0:e0 + 1]]
+            cursor = e0 + 1
+        if cursor < text.shape[1]:
+            chunks.append(text[:, cursor:])
+        inputs_embeds = torch.cat(chunks, dim=1)
+        mask = torch.ones((1, inputs_embeds.shape[1]), dtype=torch.long, device=self.device)
+        return inputs_embeds, mask
 
     def _load_bev(self, bev) -> torch.Tensor:
         if isinstance(bev, (str, Path)):
