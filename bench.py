@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE pass of the hot path (lidar_vision_vqa_amd.pipeline.FusionPipeline) over one batch of
-`--scenes` synthetic scenes per GPU (default 16): points and image-patch tokens are already resident in HBM when the
+`--scenes` synthetic scenes per GPU (default 32): points and image-patch tokens are already resident in HBM when the
 timed region starts.  Workload = BASELINE.json configs[1]: 32 768-point scenes, 0.1 m
 voxel grid, 196 ViT-B/16 patches, d=768, 12 heads, bf16 MFMA.  Scenes shard one batch per rank with no
 data-path collective; the only exchange is one RCCL all-reduce(SUM) per step of a fused fp32 buffer
@@ -46,7 +46,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--scenes", type=int, default=16, help="scenes per GPU per step (throughput: 4 -> 359k, 8 -> 373k, 16 -> 390k tokens/s)")
+    ap.add_argument("--scenes", type=int, default=32,
+                    help="scenes per GPU per step (same box: 16 -> 396 k, 24 -> 392 k, 32 -> 408 k, 48 -> 402 k, 64 -> 409 k fused tokens/s; 4 -> 359 k, 8 -> 373 k)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (bf16x3, headline cross-attn)")
