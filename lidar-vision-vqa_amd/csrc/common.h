@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <initializer_list>
 #include "../../include/lvq.h"
 
 #define LVQ_WAVE 64
@@ -12,6 +14,35 @@ static inline hipStream_t lvq_s(lvq_stream_t s) { return (hipStream_t)s; }
 static inline int lvq_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? LVQ_OK : LVQ_ELAUNCH;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (function, DEVICE): a process-wide "done" flag leaves the kernels of a
+// second GPU at the 64 KB default (launch failure there).  One LvqLdsOnce per call site remembers, per device, whether the
+// attribute was set; racing threads both set it (idempotent).
+struct LvqLdsOnce { std::atomic<uint64_t> tried{0}, ok{0}; };
+static inline bool lvq_ensure_lds(LvqLdsOnce &st, std::initializer_list<const void *> funcs, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const uint64_t bit = 1ull << (dev & 63);
+    if (st.tried.load(std::memory_order_acquire) & bit) return (st.ok.load(std::memory_order_acquire) & bit) != 0;
+    bool good = true;
+    for (const void *f : funcs) good = (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) && good;
+    if (!good) (void)hipGetLastError();
+    if (good) st.ok.fetch_or(bit, std::memory_order_release);
+    st.tried.fetch_or(bit, std::memory_order_release);
+    return good;
+}
+// compute units of the CURRENT device (cached per device id)
+static inline int lvq_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    int v = cache[dev & 63].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cache[dev & 63].store(v, std::memory_order_relaxed);
+    return v;
 }
 
 static inline int64_t lvq_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

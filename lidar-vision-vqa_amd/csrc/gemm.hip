@@ -49,7 +49,6 @@ struct GemmArgs {
     float *c32;
     uint16_t *c16, *c16lo;
     int ntx;            // tiles along N
-    int64_t ntiles;     // persistent kernel: total tiles of one batch slice
     int vec_epilogue;   // every C-side pointer / stride is 8-element aligned -> LDS-transposed 16-byte stores
     int stream_c;       // C (and the residual) is large and not re-read by this launch: non-temporal loads / stores
 };
@@ -662,226 +661,6 @@ __global__ void __launch_bounds__(512) k_gemm_256(GemmArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Persistent 256x128 GEMM (8 waves, 3-stage LDS ring, counted vmcnt) for the big projections.
-// One workgroup per CU walks a strided sequence of tiles.  The ring keeps running across tile boundaries: the
-// first two K-stages of the NEXT tile are issued BEFORE the current tile's epilogue, so the epilogue's LDS
-// transpose + stores overlap the next prologue's HBM latency (for K = 768 the non-overlapped prologue +
-// epilogue were ~1/3 of the tile time).  The epilogue slab lives in the ring slot that was consumed last.
-// Tile order: in each round of gridDim.x tiles, the 32 workgroups of one XCD (blockIdx % 8) take 32
-// CONSECUTIVE tiles (N fastest), so the tiles sharing an A row-panel hit the same L2.
-// ---------------------------------------------------------------------------------------------------------
-template <int GELU>
-__global__ void __launch_bounds__(512) k_gemm_persist(GemmArgs g) {
-    constexpr int BM = 256, BN = 128, BK = 64, NW = 8;
-    constexpr int TM = 4, TN = 4, WTM = 64;
-    constexpr int STAGE = (BM + BN) * 128;
-    constexpr int NLOADS = BM / (8 * NW) + BN / (8 * NW);   // global_load_lds per wave per stage (6)
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int64_t z = blockIdx.z;
-    const int nk = g.K / BK;
-    const int n_it = nk * g.nseg;
-    const int G = gridDim.x;
-    const int gx = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);   // position inside a round (G % 8 == 0)
-
-    // segment bases as SGPR deltas + in-order (segment, k0) state: see k_gemm_bf16
-    const int64_t dA1 = g.a[1] - g.a[0], dA2 = g.a[2] - g.a[0], dW1 = g.w[1] - g.w[0], dW2 = g.w[2] - g.w[0];
-    int d_seg = 0, d_k0 = 0;
-    auto stage_dma = [&](int64_t m0, int n0, int buf) __attribute__((always_inline)) {
-        const int seg = d_seg, k0 = d_k0;
-        d_k0 += BK;
-        if (d_k0 >= nk * BK) { d_k0 = 0; ++d_seg; }
-        const uint16_t *A = (g.a[0] + (seg == 0 ? (int64_t)0 : seg == 1 ? dA1 : dA2)) + z * g.a_bs;
-        const uint16_t *W = (g.w[0] + (seg == 0 ? (int64_t)0 : seg == 1 ? dW1 : dW2)) + z * g.w_bs;
-        uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
-        const int r8 = lane >> 3, pch = lane & 7;
-#pragma unroll
-        for (int i = 0; i < BM / (8 * NW); ++i) {
-            const int piece = i * NW + wid, row = piece * 8 + r8;
-            int64_t gm = m0 + row;
-            gm = gm < g.M ? gm : g.M - 1;
-            const uint16_t *src = A + gm * g.lda + k0 + ((pch ^ ((row >> 1) & 7)) << 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(sa + piece * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < BN / (8 * NW); ++i) {
-            const int piece = i * NW + wid, row = piece * 8 + r8;
-            int gn = n0 + row;
-            gn = gn < g.N ? gn : g.N - 1;
-            const uint16_t *src = W + (int64_t)gn * g.ldw + k0 + ((pch ^ ((row >> 1) & 7)) << 3);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(sb + piece * 1024), 16, 0, 0);
-        }
-    };
-    auto tile_of = [&](int round, int64_t &m0, int &n0) __attribute__((always_inline)) -> bool {
-        const int64_t t = (int64_t)round * G + gx;
-        if (t >= g.ntiles) return false;
-        m0 = (t / g.ntx) * BM;
-        n0 = (int)(t % g.ntx) * BN;
-        return true;
-    };
-    auto read_frags = [&](int buf, int ks, bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) __attribute__((always_inline)) {
-        const uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = wm * WTM + i * 16 + (lane & 15);
-            const int ch = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
-            af[i] = *reinterpret_cast<const bf16x8 *>(sa + row * 128 + ch * 16);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int row = wn * (BN / 2) + j * 16 + (lane & 15);
-            const int ch = (ks * 4 + (lane >> 4)) ^ ((row >> 1) & 7);
-            bfr[j] = *reinterpret_cast<const bf16x8 *>(sb + row * 128 + ch * 16);
-        }
-    };
-
-    int64_t m0 = 0, nm0 = 0;
-    int n0 = 0, nn0 = 0;
-    int round = 0, buf = 0;
-    bool have = tile_of(0, m0, n0);
-    if (have) {
-        stage_dma(m0, n0, 0);
-        if (n_it > 1) stage_dma(m0, n0, 1);
-    }
-    while (have) {
-        f32x4 acc[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        auto mma = [&](bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        };
-        // stage 0 of this tile has landed (stores of the previous epilogue drain here too: vmcnt is in-order)
-        if (n_it > 1) __builtin_amdgcn_s_waitcnt((NLOADS & 15) | 0x70 | ((NLOADS >> 4) << 14));
-        else          __builtin_amdgcn_s_waitcnt(0x0070);
-        __builtin_amdgcn_s_barrier();
-        bf16x8 a0[TM], b0[TN], a1[TM], fb1[TN];
-        read_frags(buf, 0, a0, b0);
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        // software-pipelined K loop, same schedule as k_gemm_bf16's 3-stage ring
-        for (int it = 0; it + 2 < n_it; ++it) {
-            int nb = buf + 2; nb = nb >= 3 ? nb - 3 : nb;
-            const int nx = buf == 2 ? 0 : buf + 1;
-            stage_dma(m0, n0, nb);
-            read_frags(buf, 1, a1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt((NLOADS & 15) | 0x70 | ((NLOADS >> 4) << 14));
-            __builtin_amdgcn_s_barrier();
-            read_frags(nx, 0, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            buf = nx;
-        }
-        if (n_it > 1) {
-            const int nx = buf == 2 ? 0 : buf + 1;
-            read_frags(buf, 1, a1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0x0070);
-            __builtin_amdgcn_s_barrier();
-            read_frags(nx, 0, a0, b0);
-            __builtin_amdgcn_sched_barrier(0);
-            mma(a1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
-            buf = nx;
-        }
-        read_frags(buf, 1, a1, fb1);
-        mma(a0, b0);
-        mma(a1, fb1);
-        __builtin_amdgcn_s_barrier();            // every wave is done reading the ring: all three slots are free
-        // prefetch the next tile's first two stages into the two slots after `buf`; the epilogue slab uses `buf`
-        const bool nhave = tile_of(round + 1, nm0, nn0);
-        int b1 = buf + 1 >= 3 ? 0 : buf + 1, b2 = b1 + 1 >= 3 ? 0 : b1 + 1;
-        if (nhave) {
-            d_seg = 0; d_k0 = 0;
-            stage_dma(nm0, nn0, b1);
-            if (n_it > 1) stage_dma(nm0, nn0, b2);
-        }
-        // ---- epilogue (LDS-transposed, 16 rows x 64 columns per wave per pass) ----
-        {
-            constexpr int HR = 16, WC = 64, LDE = WC + 4, CPR = WC / 8;
-            static_assert(NW * HR * LDE * 4 <= STAGE, "epilogue slab must fit in one ring slot");
-            float *ep = reinterpret_cast<float *>(smem + buf * STAGE) + wid * (HR * LDE);
-#pragma unroll
-            for (int ii = 0; ii < TM; ++ii) {
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        ep[((lane >> 4) * 4 + r) * LDE + j * 16 + (lane & 15)] = acc[ii][j][r];
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-                for (int p = 0; p < (HR * CPR) / 64; ++p) {
-                    const int q = p * 64 + lane, rr = q / CPR, c8 = q % CPR;
-                    const int64_t row = m0 + wm * WTM + ii * 16 + rr;
-                    const int col = n0 + wn * WC + c8 * 8;
-                    float v[8];
-                    *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8);
-                    *reinterpret_cast<float4 *>(v + 4) = *reinterpret_cast<const float4 *>(ep + rr * LDE + c8 * 8 + 4);
-                    if (row < g.M && col < g.N) {
-                        if (g.bias) {
-                            const float4 b0 = *reinterpret_cast<const float4 *>(g.bias + col), b1v = *reinterpret_cast<const float4 *>(g.bias + col + 4);
-                            v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1v.x; v[5] += b1v.y; v[6] += b1v.z; v[7] += b1v.w;
-                        }
-                        if (GELU) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-                        }
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] *= g.alpha;
-                        const int64_t o = z * g.c_bs + row * g.ldc + col;
-                        if (g.residual) {
-                            const float4 r0 = *reinterpret_cast<const float4 *>(g.residual + o), r1 = *reinterpret_cast<const float4 *>(g.residual + o + 4);
-                            v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-                        }
-                        if (g.rowtab) {
-                            const float *t = g.rowtab + (row % g.rowtab_rows) * g.N + col;
-                            const float4 t0 = *reinterpret_cast<const float4 *>(t), t1 = *reinterpret_cast<const float4 *>(t + 4);
-                            v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
-                        }
-                        if (g.c32) {
-                            *reinterpret_cast<float4 *>(g.c32 + o) = *reinterpret_cast<float4 *>(v);
-                            *reinterpret_cast<float4 *>(g.c32 + o + 4) = *reinterpret_cast<float4 *>(v + 4);
-                        }
-                        if (g.c16) {
-                            const uint4 hb = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
-                            *reinterpret_cast<uint4 *>(g.c16 + o) = hb;
-                            if (g.c16lo) {
-                                const uint4 lb = make_uint4(pack_bf16(v[0] - __uint_as_float(hb.x << 16), v[1] - __uint_as_float(hb.x & 0xffff0000u)),
-                                                            pack_bf16(v[2] - __uint_as_float(hb.y << 16), v[3] - __uint_as_float(hb.y & 0xffff0000u)),
-                                                            pack_bf16(v[4] - __uint_as_float(hb.z << 16), v[5] - __uint_as_float(hb.z & 0xffff0000u)),
-                                                            pack_bf16(v[6] - __uint_as_float(hb.w << 16), v[7] - __uint_as_float(hb.w & 0xffff0000u)));
-                                *reinterpret_cast<uint4 *>(g.c16lo + o) = lb;
-                            }
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        have = nhave;
-        m0 = nm0; n0 = nn0;
-        buf = b1;
-        ++round;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
 // Row-complete GEMM with LayerNorm fused into the epilogue (VATLiDAR token path, vat_lidar.py:222-248):
 //     Y = LayerNorm(A W^T + bias) * gamma + beta + post[row % post_rows]        -> bf16 (hi, lo)
 // One workgroup owns 64 rows x ALL N columns (N <= 1024), so the row statistics never leave registers and the
@@ -1198,20 +977,13 @@ __global__ void __launch_bounds__(LNR_WAVES * 64) k_gemm_ln_rows(GemmLnArgs g, i
 template <int NG> int launch_gemm_ln_rows(const GemmLnArgs &g, hipStream_t st) {
     constexpr int SB = 4;
     const size_t lds = (size_t)NG * 64 * 128 + (size_t)3 * NG * 64 * sizeof(float);
-    static int ok = -1;
-    if (ok < 0) ok = hipFuncSetAttribute((const void *)k_gemm_ln_rows<NG, SB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); return LVQ_EUNSUPPORTED; }
+    static LvqLdsOnce once;
+    if (!lvq_ensure_lds(once, {(const void *)k_gemm_ln_rows<NG, SB>}, lds)) return LVQ_EUNSUPPORTED;
     int scenes = 1;
     int64_t rps = g.M;
     if (g.post && g.M > g.post_rows) { scenes = (int)(g.M / g.post_rows); rps = g.post_rows; }
     const int64_t n_pt = lvq_cdiv(rps, 16);
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = lvq_cu_count();
     const int64_t want = lvq_cdiv(n_pt, LNR_WAVES);
     const unsigned grid = (unsigned)(want < n_cu ? want : n_cu);
     hipLaunchKernelGGL((k_gemm_ln_rows<NG, SB>), dim3(grid), dim3(LNR_WAVES * 64), lds, st, g, (int)n_pt, scenes, rps);
@@ -1220,11 +992,8 @@ template <int NG> int launch_gemm_ln_rows(const GemmLnArgs &g, hipStream_t st) {
 
 template <int NT16> int launch_gemm_ln(const GemmLnArgs &g, hipStream_t st) {
     const size_t lds = (size_t)(NT16 * 16 + 64) * 40 * sizeof(uint16_t);      // >= 4 waves x 16 x 68 floats (17 KB) for every NT16 >= 12
-    static bool done = false;
-    if (!done && lds > 64 * 1024) {
-        hipFuncSetAttribute((const void *)k_gemm_ln<NT16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        done = true;
-    }
+    static LvqLdsOnce once;
+    if (lds > 64 * 1024 && !lvq_ensure_lds(once, {(const void *)k_gemm_ln<NT16>}, lds)) return LVQ_EUNSUPPORTED;
     hipLaunchKernelGGL(k_gemm_ln<NT16>, dim3((unsigned)lvq_cdiv(g.M, 64)), dim3(256), lds, st, g);
     return lvq_launch_status();
 }
@@ -1470,57 +1239,27 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
     if (batch > 65535) return LVQ_EUNSUPPORTED;
     // 256x256 / two 64-KiB slots: 2/3 of the L2->LDS fill bytes of the 256x128 tile (the bound on these projections);
     // whole tiles only, and enough of them that the coarser grid still fills the 256 CUs several times over
-    static int ok256 = -1;          // -1 unknown, 0 the runtime refused 160 KiB of dynamic LDS, 1 usable
+    static LvqLdsOnce once256;      // per device: did the runtime grant 160 KiB of dynamic LDS?
     if (dma && g.vec_epilogue && m % 256 == 0 && n % 256 == 0 && (m / 256) * (n / 256) * batch >= 1024 &&
-        (m / 256) * (n / 256) <= 0x7fffffff && ok256 != 0 && getenv("LVQ_GEMM_NO256X256") == nullptr && getenv("LVQ_GEMM_NO256") == nullptr) {
+        (m / 256) * (n / 256) <= 0x7fffffff && getenv("LVQ_GEMM_NO256X256") == nullptr && getenv("LVQ_GEMM_NO256") == nullptr) {
         const size_t lds = (size_t)5 * 256 * 128;              // A ring 3 x 32 KiB + W ring 2 x 32 KiB
-        if (ok256 < 0)
-            ok256 = hipFuncSetAttribute((const void *)k_gemm_256<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                    hipFuncSetAttribute((const void *)k_gemm_256<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                    hipFuncSetAttribute((const void *)k_gemm_256<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-                    hipFuncSetAttribute((const void *)k_gemm_256<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-        if (ok256) {
+        if (lvq_ensure_lds(once256, {(const void *)k_gemm_256<0, 0>, (const void *)k_gemm_256<1, 0>, (const void *)k_gemm_256<0, 1>,
+                                     (const void *)k_gemm_256<1, 1>}, lds)) {
             g.ntx = (int)(n / 256);
-            g.ntiles = (m / 256) * (n / 256);
-            dim3 grid((unsigned)g.ntiles, 1, (unsigned)batch);
+            dim3 grid((unsigned)((m / 256) * (n / 256)), 1, (unsigned)batch);
             const bool ant = g.ntx <= 8;
             if (ge) { if (ant) hipLaunchKernelGGL((k_gemm_256<1, 1>), grid, dim3(512), lds, st, g); else hipLaunchKernelGGL((k_gemm_256<1, 0>), grid, dim3(512), lds, st, g); }
             else    { if (ant) hipLaunchKernelGGL((k_gemm_256<0, 1>), grid, dim3(512), lds, st, g); else hipLaunchKernelGGL((k_gemm_256<0, 0>), grid, dim3(512), lds, st, g); }
             return lvq_launch_status();
         }
-        (void)hipGetLastError();
     }
     if (huge) {
         const int64_t tiles = lvq_cdiv(n, 128) * lvq_cdiv(m, 256);
         if (tiles > 0x7fffffff) return LVQ_EUNSUPPORTED;
         g.ntx = (int)lvq_cdiv(n, 128);
-        g.ntiles = tiles;
         const size_t lds = (size_t)3 * (256 + 128) * 128;
-        static bool attr_done = false;
-        if (!attr_done) {
-            hipFuncSetAttribute((const void *)k_gemm_bf16<256, 128, 1, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipFuncSetAttribute((const void *)k_gemm_bf16<256, 128, 1, 1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipFuncSetAttribute((const void *)k_gemm_persist<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipFuncSetAttribute((const void *)k_gemm_persist<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
-        // Persistent cross-tile-pipelined variant: measured 617 vs 642 TFLOP/s for the plain 3-stage kernel on
-        // (1M x 1536 x 768) -- prologue/epilogue overlap is not the limiter -- so it is opt-in only.
-        if (g.vec_epilogue && getenv("LVQ_GEMM_PERSIST") != nullptr) {
-            static int n_cu = 0;
-            if (!n_cu) {
-                int dev = 0;
-                hipDeviceProp_t prop;
-                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-                if (n_cu <= 0) n_cu = 256;
-                n_cu = n_cu / 8 * 8;            // the round layout assumes a multiple of the 8 XCDs
-                if (n_cu < 8) n_cu = 8;
-            }
-            dim3 grid((unsigned)n_cu, 1, (unsigned)batch);
-            if (ge) hipLaunchKernelGGL(k_gemm_persist<1>, grid, dim3(512), lds, st, g);
-            else    hipLaunchKernelGGL(k_gemm_persist<0>, grid, dim3(512), lds, st, g);
-            return lvq_launch_status();
-        }
+        static LvqLdsOnce once;
+        if (!lvq_ensure_lds(once, {(const void *)k_gemm_bf16<256, 128, 1, 0, 8>, (const void *)k_gemm_bf16<256, 128, 1, 1, 8>}, lds)) return LVQ_ELAUNCH;
         dim3 grid((unsigned)tiles, 1, (unsigned)batch);
         if (ge) hipLaunchKernelGGL((k_gemm_bf16<256, 128, 1, 1, 8>), grid, dim3(512), lds, st, g);
         else    hipLaunchKernelGGL((k_gemm_bf16<256, 128, 1, 0, 8>), grid, dim3(512), lds, st, g);

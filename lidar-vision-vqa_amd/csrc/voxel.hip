@@ -597,6 +597,8 @@ extern "C" int lvq_voxelize_hard(const float *pts, const int32_t *scene_off, int
     }
     int64_t need = n_points < (int64_t)n_scenes * max_voxels ? n_points : (int64_t)n_scenes * max_voxels;
     if (voxel_capacity < need || !pts || !voxels || !coords_bzyx || !num_pts) return LVQ_EINVAL;
+    // the contract is the QUERIED size (whichever implementation ends up running): checked before anything is launched
+    if (!ws || ws_bytes < lvq_voxelize_hard_workspace_bytes(n_points, n_scenes)) return LVQ_EWORKSPACE;
     // default: hash-balanced slabs (voxel_hashed.hip); shapes it does not take go to the slab-binned path, then to the
     // global-hash kernels below.  LVQ_VOXEL_BINNED / LVQ_VOXEL_LEGACY force the older paths (tests, A/B timing).
     if (!break_on_cap && getenv("LVQ_VOXEL_LEGACY") == nullptr && getenv("LVQ_VOXEL_BINNED") == nullptr) {
@@ -661,6 +663,7 @@ extern "C" int lvq_voxelize_mean(const float *pts, const int32_t *scene_off, int
     }
     const int64_t need = n_points < (int64_t)n_scenes * max_voxels ? n_points : (int64_t)n_scenes * max_voxels;
     if (voxel_capacity < need || !pts || !voxel_features || !coords_bzyx || !num_pts) return LVQ_EINVAL;
+    if (!ws || ws_bytes < lvq_voxelize_hard_workspace_bytes(n_points, n_scenes)) return LVQ_EWORKSPACE;
     return lvq_hashed_voxelize_mean(pts, scene_off, n_points, n_scenes, c, range_host, vsize_host, grid_host, max_pts, max_voxels,
                                     voxel_features, coords_bzyx, num_pts, scene_voxel_off, ws, ws_bytes, st);
 }
@@ -701,6 +704,7 @@ extern "C" int lvq_voxelize_dynamic(const float *pts, int64_t n, int c, int batc
         return lvq_launch_status();
     }
     if (!pts || !unq_inv || !unq_key || !unq_cnt || !coords_bzyx) return LVQ_EINVAL;
+    if (!ws || ws_bytes < lvq_voxelize_dynamic_workspace_bytes(n, batch_size, grid_host, ndim)) return LVQ_EWORKSPACE;
     if (getenv("LVQ_VOXEL_LEGACY") == nullptr) {       // slab-binned path first; the two-level-bitmap kernels below are the fallback
         const int rc = lvq_binned_voxelize_dynamic(pts, n, c, batch_size, range_host, vsize_host, grid_host, ndim, unq_inv, pt_coords,
                                                    unq_key, unq_cnt, coords_bzyx, counts, ws, ws_bytes, st);

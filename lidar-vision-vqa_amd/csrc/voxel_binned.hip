@@ -741,11 +741,8 @@ int lvq_binned_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t
                        w.gstart, w.cursor, w.sidx, w.soff, w.spts, (const int32_t *)nullptr, (int32_t *)nullptr);
     const int nw = 1 << (cfg.logslab - 6);
     const size_t lds = sizeof(unsigned long long) * nw + sizeof(int32_t) * nw + sizeof(int32_t) * (4 * HARD_VCAP + HARD_PCAP);
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void *)k_hard_slab, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-        attr = true;
-    }
+    static LvqLdsOnce once;
+    if (!lvq_ensure_lds(once, {(const void *)k_hard_slab}, 160 * 1024 - 256)) return LVQ_ELAUNCH;
     hipLaunchKernelGGL(k_hard_slab_small, dim3(cfg.nslabs), dim3(256), 0, st, cfg, w);
     if (n > SMALL_PCAP) hipLaunchKernelGGL(k_hard_slab, dim3(cfg.nslabs), dim3(SLAB_NT), lds, st, cfg, max_pts, w);
     hipLaunchKernelGGL(k_flags_to_words, dim3((unsigned)lvq_cdiv(nwords * 64, 256)), dim3(256), 0, st, w.fbytes, (int)(nwords * 64), w.fmask,

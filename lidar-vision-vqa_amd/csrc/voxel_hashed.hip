@@ -681,12 +681,8 @@ static int hashed_voxelize(bool mean, const float *pts, const int32_t *scene_off
     if (!arena.ok) return LVQ_EWORKSPACE;
     Geom g;
     for (int j = 0; j < 3; ++j) { g.lo[j] = range_host[j]; g.vs[j] = vsize_host[j]; g.grid[j] = grid_host[j]; }
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute((const void *)k_slab<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute((const void *)k_slab<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr = true;
-    }
+    static LvqLdsOnce once;
+    if (!lvq_ensure_lds(once, {(const void *)k_slab<false>, (const void *)k_slab<true>}, 96 * 1024)) return LVQ_ELAUNCH;
     const unsigned nb = (unsigned)lvq_cdiv(n, BIN_NT * BIN_PPT);
     const float4 *p4 = reinterpret_cast<const float4 *>(pts);
     hipMemsetAsync(w.cursor, 0, sizeof(int32_t) * (MAX_SLABS + 64), st);

@@ -58,6 +58,42 @@ def test_prefix_assembly_and_answer_logits(prec, tol):
 
 
 @pytest.mark.parametrize("prec,tol", [("bf16x3", 1e-3), ("bf16", None)])
+def test_head_reference_geometry(prec, tol):
+    """The reference decoder's geometry (Qwen2.5-0.5B: d = 896, 14 / 2 heads, head_dim 64, inter 4864; 4 layers, vocab 8192) on
+    BASELINE configs[4]'s sequence -- 576 vision + 256 LiDAR prefix tokens, prompt, 32 answer positions (L = 880): answer logits
+    within 1e-3 of transformers' Qwen2 (golden head_ref_prefix: head slice elementwise, log-sum-exp and L2 norm of every row,
+    arg-max ids), labels exact, loss."""
+    from lidar_vision_vqa_amd import head
+    hc = cases.HEAD_REF_CASE
+    g = golden("head_ref_prefix")
+    B, d = hc["B"], hc["d"]
+    base = head.StandInHead(hc["vocab"], d, hc["inter"], hc["n_heads"], hc["n_kv_heads"], hc["n_layers"], hc["rms_eps"],
+                            hc["rope_theta"]).to(DEV).eval()
+    sd = {k: torch.from_numpy(synth.seeded_array(k, tuple(v.shape), hc["seed"])) for k, v in base.state_dict().items() if k != "lm_head.weight"}
+    sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
+    base.load_state_dict(sd)
+    base.precision = prec
+    pl = torch.from_numpy(synth.randn((B, hc["nq_lidar"], d), hc["seed"] + 1)).to(DEV)
+    pv = torch.from_numpy(synth.randn((B, hc["nq_vision"], d), hc["seed"] + 2)).to(DEV)
+    p_ids, a_ids = torch.from_numpy(g["p_ids"]).to(DEV), torch.from_numpy(g["a_ids"]).to(DEV)
+    with torch.no_grad():
+        E = base.embed(torch.arange(4, device=DEV))
+        inp, attn, labels = head.assemble_prefix(pv, pl, E, base.embed(p_ids), base.embed(a_ids), a_ids, 0.2)
+        out = base(inputs_embeds=inp, attention_mask=attn, labels=labels)
+    assert inp.shape[1] == 880 and np.array_equal(labels.cpu().numpy(), g["labels"])
+    assert np.abs(inp.double().sum(-1).cpu().numpy() - g["inputs_embeds_sum"]).max() < 1e-3
+    al = out.logits[:, -hc["n_answer"]:].cpu()
+    if tol is None:
+        tol = 2e-2 * float(np.abs(g["answer_logits_head"]).max())
+    assert np.abs(al[:, :, :512].numpy() - g["answer_logits_head"]).max() < tol
+    assert np.abs(torch.logsumexp(al.double(), -1).numpy() - g["answer_lse"]).max() < tol
+    assert np.abs(al.double().pow(2).sum(-1).sqrt().numpy() - g["answer_row_norm"]).max() < tol * np.sqrt(hc["vocab"])
+    if prec == "bf16x3":
+        assert np.array_equal(al.argmax(-1).numpy().astype(np.int32), g["answer_argmax"])
+    assert abs(float(out.loss) - float(g["loss"])) < tol
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16x3", 1e-3), ("bf16", None)])
 def test_greedy_generate_vs_transformers(prec, tol):
     """SURVEY 8f row f4 (inference_engine.py:283-296): greedy decoding with the KV cache == transformers'
     `generate(inputs_embeds=, do_sample=False)` on the seeded Qwen2 stand-in: token ids exactly (the golden top-1 / top-2

@@ -145,3 +145,57 @@ def test_dynamic_pillar_matches_hard_pillar_when_uncapped():
                        torch.sqrt(sd["pfn_layers.0.norm.running_var"] + 1e-3) * sd["pfn_layers.0.norm.weight"])
     expect = torch.maximum(dyn["features"], shift.unsqueeze(0))
     assert (h - expect).abs().max().item() < 1e-4
+
+
+def _np_hard_voxelize(points, rng, vs, T, mv):
+    """Independent numpy/python formulation of the same published loop (fp32 subtract, fp32 IEEE divide, floor; first
+    appearance order; `continue` cap) -- a second implementation to hold voxel_oracle.c against at the reference's real config."""
+    lo = np.asarray(rng[:3], np.float32)
+    v = np.asarray(vs, np.float32)
+    grid = np.round((np.asarray(rng[3:], np.float32) - lo) / v).astype(np.int64)
+    c = np.floor((points[:, :3].astype(np.float32) - lo) / v)
+    ok = ((c >= 0) & (c < grid.astype(np.float32))).all(axis=1)
+    ci = c.astype(np.int64)
+    ids, coords, slots = {}, [], []
+    for i in np.nonzero(ok)[0]:
+        key = (int(ci[i, 2]), int(ci[i, 1]), int(ci[i, 0]))
+        vid = ids.get(key)
+        if vid is None:
+            if len(coords) >= mv:
+                continue
+            vid = len(coords)
+            ids[key] = vid
+            coords.append(key)
+            slots.append([])
+        if len(slots[vid]) < T:
+            slots[vid].append(i)
+    vox = np.zeros((len(coords), T, points.shape[1]), np.float32)
+    for vid, idx in enumerate(slots):
+        vox[vid, :len(idx)] = points[idx]
+    return vox, np.asarray(coords, np.int32).reshape(-1, 3), np.asarray([len(s) for s in slots], np.int32)
+
+
+def test_hard_voxelizer_voxelnext_config_two_implementations():
+    """The configuration the reference runs (cbgs_voxel0075_voxelnext.yaml:6,60-66): +-54 m, 0.075 m (not an fp32 number),
+    T = 10, 120 000 voxels, with points exactly ON cell edges lo + k * 0.075 and one ulp either side: the C oracle and the numpy
+    formulation must agree on every index, count and payload bit."""
+    rng = [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]
+    vs = (0.075, 0.075, 0.2)
+    r = np.random.default_rng(12)
+    pts = synth.scene_points("C", 20000, 4321)
+    pts[:, :2] *= np.float32(54.0 / 51.2)
+    k = r.integers(0, 1441, size=(1500, 2))
+    edge = (np.float32(-54.0) + k.astype(np.float32) * np.float32(0.075)).astype(np.float32)
+    xy = np.concatenate((edge, np.nextafter(edge, np.float32(-np.inf)), np.nextafter(edge, np.float32(np.inf)),
+                         (-54.0 + k * 0.075).astype(np.float32)))
+    extra = np.concatenate((xy, r.uniform(-5, 3, (len(xy), 1)).astype(np.float32), r.random((len(xy), 1)).astype(np.float32)), axis=1)
+    pts = np.concatenate((pts, extra.astype(np.float32)))
+    pts = np.ascontiguousarray(pts[r.permutation(len(pts))])
+    for mv in (120000, 5000):
+        ov, oc, on = LO.VoxelGenerator(vs, rng, 4, 10, mv).generate(pts)
+        nv, nc, nn = _np_hard_voxelize(pts, rng, vs, 10, mv)
+        assert np.array_equal(oc, nc) and np.array_equal(on, nn)
+        assert np.array_equal(ov.view(np.uint32), nv.view(np.uint32))
+    # the edge points really do straddle cells: both floor outcomes occur among the +-1 ulp variants
+    c = np.floor((xy - np.float32(-54.0)) / np.float32(0.075))
+    assert len(np.unique((c[:1500] - c[1500:3000]).ravel())) >= 2

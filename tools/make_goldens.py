@@ -9,6 +9,7 @@ and stores the OUTPUTS.  Inputs and weights are regenerated from the seeds by th
 fixtures hold data only -- no reference source, bytecode or text travels with the repo.
 
     python tools/make_goldens.py            # rewrites tests/golden/
+    python tools/make_goldens.py --only _ref  # only fixtures whose name contains "_ref" (the reference-geometry cases)
 """
 from __future__ import annotations
 
@@ -74,6 +75,18 @@ def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
+ONLY = None
+
+
+def want(name: str) -> bool:
+    return ONLY is None or ONLY in name
+
+
+def sliced(out: torch.Tensor) -> dict:
+    """Large outputs: first rows, every 16th row, per-row L2 norm and sum of ALL rows (cases.slice_rows)."""
+    return cases.slice_rows(out.reshape(-1, out.shape[-1]).numpy())
+
+
 def save(name, **arrs):
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrs.items()})
@@ -82,12 +95,17 @@ def save(name, **arrs):
 
 @torch.no_grad()
 def main():
+    global ONLY
+    if "--only" in sys.argv:
+        ONLY = sys.argv[sys.argv.index("--only") + 1]
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     R = import_reference()
 
     print("VATBlock")
     for name, c in cases.VAT_BLOCK_CASES.items():
+        if not want("vat_block_" + name):
+            continue
         m = synth.load_seeded(R.VATBlock(c["d"], c["h"], c["dff"], 0.1).eval(), c["seed"])
         q = t(synth.randn((c["B"], c["Nq"], c["d"]), c["seed"] + 1000))
         kv = t(synth.randn((c["B"], c["Nk"], c["d"]), c["seed"] + 2000))
@@ -95,26 +113,44 @@ def main():
 
     print("VATLiDAR")
     for name, c in cases.VAT_LIDAR_CASES.items():
+        if not want("vat_lidar_" + name):
+            continue
         m = synth.load_seeded(R.VATLiDAR(c["c_in"], c["d"], c["nq"], c["L"], c["h"]).eval(), c["seed"])
         bev = t(synth.randn((c["B"], c["c_in"], c["H"], c["W"]), c["seed"] + 1000))
         geom, sid = m._grid(c["H"], c["W"], torch.device("cpu"))
-        save("vat_lidar_" + name, out=m(bev), sid=sid.to(torch.int32), geom=geom)
+        out = m(bev)
+        if c.get("sliced"):
+            save("vat_lidar_" + name, sid=sid.to(torch.int32), geom_sum=geom.double().sum(0), **sliced(out))
+        elif c["H"] * c["W"] > 10000:      # the [HW, 5] geometry table is regenerated by the tests; keep its column sums
+            save("vat_lidar_" + name, out=out, sid=sid.to(torch.int32), geom_sum=geom.double().sum(0))
+        else:
+            save("vat_lidar_" + name, out=out, sid=sid.to(torch.int32), geom=geom)
 
     print("VATVision")
     for name, c in cases.VAT_VISION_CASES.items():
+        if not want("vat_vision_" + name):
+            continue
         m = R.VATVision(c["d_in"], c["d_model"], c["n_in"], c["cf"], c["L"], c["h"], use_per_view_query=c["per_view"]).eval()
         synth.load_seeded(m, c["seed"])
         kv = t(synth.randn((c["B"], c["n_in"], c["d_in"]), c["seed"] + 1000))
-        save("vat_vision_" + name, out=m(kv))
+        out = m(kv)
+        if c.get("sliced"):
+            save("vat_vision_" + name, **sliced(out))
+        else:
+            save("vat_vision_" + name, out=out)
 
     print("VisionAdapter")
     for name, c in cases.VISION_ADAPTER_CASES.items():
+        if not want("vision_adapter_" + name):
+            continue
         m = synth.load_seeded(R.VisionAdapter(c["d_in"], 0.1).eval(), c["seed"])
         views = [t(synth.randn((c["hw"], c["d_in"]), c["seed"] + 100 + v)) for v in range(6)]
         save("vision_adapter_" + name, out=m(views))
 
     print("sdp_attention (deepencoder/sam_vary_sdpa.py)")
     for name, c in cases.SDPA_CASES.items():
+        if not want("sdpa_" + name):
+            continue
         q = t(synth.randn((c["B"], c["H"], c["S"], c["D"]), c["seed"]))
         k = t(synth.randn((c["B"], c["H"], c["S"], c["D"]), c["seed"] + 1))
         v = t(synth.randn((c["B"], c["H"], c["S"], c["D"]), c["seed"] + 2))
@@ -122,15 +158,18 @@ def main():
         save("sdpa_" + name, out=R.sam_sdp(q, k, v, mask))
 
     print("MlpProjector(linear) + fuse (deepencoder_infer.py:505-511)")
-    proj = synth.load_seeded(R.MlpProjector(Cfg(projector_type="linear", input_dim=256, n_embed=192)).eval(), 91)
-    clip = t(synth.randn((1, 17, 128), 92))
-    sam = t(synth.randn((1, 128, 4, 4), 93))
-    fused = proj(torch.cat((clip[:, 1:], sam.flatten(2).permute(0, 2, 1)), dim=-1))
-    save("deepencoder_fuse", out=fused)
+    if want("deepencoder_fuse"):
+        proj = synth.load_seeded(R.MlpProjector(Cfg(projector_type="linear", input_dim=256, n_embed=192)).eval(), 91)
+        clip = t(synth.randn((1, 17, 128), 92))
+        sam = t(synth.randn((1, 128, 4, 4), 93))
+        fused = proj(torch.cat((clip[:, 1:], sam.flatten(2).permute(0, 2, 1)), dim=-1))
+        save("deepencoder_fuse", out=fused)
 
     print("MeanVFE / PillarVFE / PointPillarScatter")
     rng_nusc = list(synth.PC_RANGE_NUSC)
     for name, c in cases.MEAN_CASES.items():
+        if not want("lidar_" + name):
+            continue
         pts = synth.scene_points(c["dist"], c["n"], c["seed"])
         pts = pts[LO.mask_points_by_range(pts, rng_nusc)]
         vox, co, num = LO.VoxelGenerator(synth.VOXEL_01, rng_nusc, 4, c["T"], c["max_voxels"]).generate(pts)
@@ -138,6 +177,8 @@ def main():
         out = R.MeanVFE(Cfg(), 4)(bd)["voxel_features"]
         save("lidar_" + name, out=out, n_voxels=np.int64(len(num)))
     for name, c in cases.PILLAR_CASES.items():
+        if not want("lidar_" + name):
+            continue
         scenes = []
         for s in range(2):
             pts = synth.scene_points(c["dist"], c["n"], c["seed"] + 100 * s)
@@ -157,39 +198,71 @@ def main():
         save("lidar_" + name, pillar_features=bd["pillar_features"], bev_sum=bev.sum(dim=(2, 3)),
              bev_nonzero=nz.to(torch.int32), bev_abs_sum=bev.abs().double().sum())
 
-    print("prefix assembly + stand-in head (validation.py:105-158 replayed)")
-    from transformers import Qwen2Config, Qwen2ForCausalLM
-    hc = cases.HEAD_CASE
-    cfg = Qwen2Config(vocab_size=hc["vocab"], hidden_size=hc["d"], intermediate_size=hc["inter"],
-                      num_attention_heads=hc["n_heads"], num_key_value_heads=hc["n_kv_heads"],
-                      num_hidden_layers=hc["n_layers"], tie_word_embeddings=True, rms_norm_eps=hc["rms_eps"],
-                      rope_theta=hc["rope_theta"], max_position_embeddings=512, attn_implementation="eager")
-    base = Qwen2ForCausalLM(cfg).eval()
-    sd = {k: t(synth.seeded_array(k, tuple(v.shape), hc["seed"])) for k, v in base.state_dict().items() if k != "lm_head.weight"}
-    sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
-    base.load_state_dict(sd)
-    B, d = hc["B"], hc["d"]
-    vl = synth.load_seeded(R.VATLiDAR(16, d, hc["nq_lidar"], 1, 4).eval(), hc["seed"] + 1)
-    va = synth.load_seeded(R.VisionAdapter(64, 0.1).eval(), hc["seed"] + 2)
-    vv = synth.load_seeded(R.VATVision(64, d, 48, 2, 1, 4).eval(), hc["seed"] + 3)
-    bev = t(synth.randn((B, 16, 10, 10), hc["seed"] + 4))
-    vision_kv = torch.stack([va([t(synth.randn((8, 64), hc["seed"] + 10 + 6 * b + v)) for v in range(6)]) for b in range(B)])
-    rng = np.random.default_rng(hc["seed"] + 5)
-    p_ids = t(rng.integers(4, hc["vocab"], size=(B, hc["n_prompt"])))
-    a_ids = t(rng.integers(4, hc["vocab"], size=(B, hc["n_answer"])))
-    E = base.get_input_embeddings()
-    prefix_lidar = vl(bev) * 0.2
-    prefix_vision = vv(vision_kv) * 0.2
-    sp = lambda i: E(torch.tensor([[i]])).expand(B, -1, -1)  # 4 special tokens = rows 0..3
-    pieces = [sp(0), prefix_vision, sp(1), sp(2), prefix_lidar, sp(3), E(p_ids)]
-    inp = torch.cat(pieces + [E(a_ids)], dim=1)
-    L = inp.size(1)
-    labels = torch.full((B, L), -100, dtype=torch.long)
-    labels[:, -a_ids.size(1):] = a_ids
-    attn = torch.ones((B, L), dtype=torch.long)
-    out = base(inputs_embeds=inp, attention_mask=attn, labels=labels)
-    save("head_prefix", prefix_lidar=prefix_lidar, prefix_vision=prefix_vision, inputs_embeds=inp,
-         labels=labels, loss=out.loss, answer_logits=out.logits[:, -hc["n_answer"]:, :], p_ids=p_ids, a_ids=a_ids)
+    if want("head_prefix"):
+        print("prefix assembly + stand-in head (validation.py:105-158 replayed)")
+        from transformers import Qwen2Config, Qwen2ForCausalLM
+        hc = cases.HEAD_CASE
+        cfg = Qwen2Config(vocab_size=hc["vocab"], hidden_size=hc["d"], intermediate_size=hc["inter"],
+                          num_attention_heads=hc["n_heads"], num_key_value_heads=hc["n_kv_heads"],
+                          num_hidden_layers=hc["n_layers"], tie_word_embeddings=True, rms_norm_eps=hc["rms_eps"],
+                          rope_theta=hc["rope_theta"], max_position_embeddings=512, attn_implementation="eager")
+        base = Qwen2ForCausalLM(cfg).eval()
+        sd = {k: t(synth.seeded_array(k, tuple(v.shape), hc["seed"])) for k, v in base.state_dict().items() if k != "lm_head.weight"}
+        sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
+        base.load_state_dict(sd)
+        B, d = hc["B"], hc["d"]
+        vl = synth.load_seeded(R.VATLiDAR(16, d, hc["nq_lidar"], 1, 4).eval(), hc["seed"] + 1)
+        va = synth.load_seeded(R.VisionAdapter(64, 0.1).eval(), hc["seed"] + 2)
+        vv = synth.load_seeded(R.VATVision(64, d, 48, 2, 1, 4).eval(), hc["seed"] + 3)
+        bev = t(synth.randn((B, 16, 10, 10), hc["seed"] + 4))
+        vision_kv = torch.stack([va([t(synth.randn((8, 64), hc["seed"] + 10 + 6 * b + v)) for v in range(6)]) for b in range(B)])
+        rng = np.random.default_rng(hc["seed"] + 5)
+        p_ids = t(rng.integers(4, hc["vocab"], size=(B, hc["n_prompt"])))
+        a_ids = t(rng.integers(4, hc["vocab"], size=(B, hc["n_answer"])))
+        E = base.get_input_embeddings()
+        prefix_lidar = vl(bev) * 0.2
+        prefix_vision = vv(vision_kv) * 0.2
+        sp = lambda i: E(torch.tensor([[i]])).expand(B, -1, -1)  # 4 special tokens = rows 0..3
+        pieces = [sp(0), prefix_vision, sp(1), sp(2), prefix_lidar, sp(3), E(p_ids)]
+        inp = torch.cat(pieces + [E(a_ids)], dim=1)
+        L = inp.size(1)
+        labels = torch.full((B, L), -100, dtype=torch.long)
+        labels[:, -a_ids.size(1):] = a_ids
+        attn = torch.ones((B, L), dtype=torch.long)
+        out = base(inputs_embeds=inp, attention_mask=attn, labels=labels)
+        save("head_prefix", prefix_lidar=prefix_lidar, prefix_vision=prefix_vision, inputs_embeds=inp,
+             labels=labels, loss=out.loss, answer_logits=out.logits[:, -hc["n_answer"]:, :], p_ids=p_ids, a_ids=a_ids)
+    if want("head_ref_prefix"):
+        # the reference decoder's geometry at BASELINE configs[4]'s sequence (cases.HEAD_REF_CASE): prefix tensors are seeded
+        # N(0,1) (the VAT modules have their own goldens), the assembly is validation.py:124-148 replayed, the head transformers' Qwen2
+        print("stand-in head at d = 896 / 14-2 heads (validation.py:124-158 replayed)")
+        from transformers import Qwen2Config, Qwen2ForCausalLM
+        hc = cases.HEAD_REF_CASE
+        cfg = Qwen2Config(vocab_size=hc["vocab"], hidden_size=hc["d"], intermediate_size=hc["inter"],
+                          num_attention_heads=hc["n_heads"], num_key_value_heads=hc["n_kv_heads"],
+                          num_hidden_layers=hc["n_layers"], tie_word_embeddings=True, rms_norm_eps=hc["rms_eps"],
+                          rope_theta=hc["rope_theta"], max_position_embeddings=2048, attn_implementation="eager")
+        base = Qwen2ForCausalLM(cfg).eval()
+        sd = {k: t(synth.seeded_array(k, tuple(v.shape), hc["seed"])) for k, v in base.state_dict().items() if k != "lm_head.weight"}
+        sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
+        base.load_state_dict(sd)
+        B, d = hc["B"], hc["d"]
+        pl = t(synth.randn((B, hc["nq_lidar"], d), hc["seed"] + 1))
+        pv = t(synth.randn((B, hc["nq_vision"], d), hc["seed"] + 2))
+        rng = np.random.default_rng(hc["seed"] + 5)
+        p_ids = t(rng.integers(4, hc["vocab"], size=(B, hc["n_prompt"])))
+        a_ids = t(rng.integers(4, hc["vocab"], size=(B, hc["n_answer"])))
+        E = base.get_input_embeddings()
+        sp = lambda i: E(torch.tensor([[i]])).expand(B, -1, -1)
+        inp = torch.cat([sp(0), pv * 0.2, sp(1), sp(2), pl * 0.2, sp(3), E(p_ids), E(a_ids)], dim=1)
+        L = inp.size(1)
+        labels = torch.full((B, L), -100, dtype=torch.long)
+        labels[:, -a_ids.size(1):] = a_ids
+        out = base(inputs_embeds=inp, attention_mask=torch.ones((B, L), dtype=torch.long), labels=labels)
+        al = out.logits[:, -hc["n_answer"]:, :]
+        save("head_ref_prefix", labels=labels, loss=out.loss, p_ids=p_ids, a_ids=a_ids, inputs_embeds_sum=inp.double().sum(-1).float(),
+             answer_logits_head=al[:, :, :512], answer_argmax=al.argmax(-1).to(torch.int32), answer_lse=torch.logsumexp(al.double(), -1).float(),
+             answer_row_norm=al.double().pow(2).sum(-1).sqrt().float())
     print("done")
 
 
