@@ -211,6 +211,11 @@ int lvq_bf16_to_f32(const lvq_bf16 *hi, const lvq_bf16 *lo, int64_t n, float alp
  *   kernel, no workspace.  Larger dh (448, 1024: the reference's 2-head defaults) or dh % 16 == 8: split
  *   path (scores GEMM -> row softmax -> PV GEMM) using the workspace; needs n_heads == n_kv_heads. */
 size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, int nkv, int dh, int precision);
+/* 1 when the long-stream kernel takes (nq, nkv, dh) without bias / mask: head_dim 64, nkv >= 4096 and a multiple of 64, query
+ * count with at most 1/8 padding to 128 / 192 rows.  Those are the shapes for which lvq_attention_bf16 accepts the "mixed" operand
+ * form q = hi + lo, k / v plain (k_lo = v_lo = NULL): Q-side rounding is common to all keys of a row and does not average out
+ * over the stream, K / V / P roundings do.  Any other shape with that operand form returns LVQ_EUNSUPPORTED. */
+int lvq_attention_stream_ok(int nq, int nkv, int dh);
 int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k, const lvq_bf16 *k_lo,
                        const lvq_bf16 *v, const lvq_bf16 *v_lo, const float *bias, int batch, int n_heads,
                        int n_kv_heads, int nq, int nkv, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride,
@@ -251,6 +256,14 @@ int lvq_rope_inplace_at(lvq_bf16 *x, lvq_bf16 *x_lo, int64_t rows, int seq_len, 
                         float theta, lvq_stream_t stream);
 /* greedy decoding: out_idx[r] = index of the first maximum of x[r, 0..n) (torch.argmax on finite logits). */
 int lvq_argmax_rows(const float *x, int64_t rows, int n, int64_t *out_idx, lvq_stream_t stream);
+/* f4  one sampling step of `base_model.generate(do_sample=True, temperature=, top_k=, top_p=)` (the reference's default call,
+ * inference_engine.py:236-240,283-296 -> transformers' TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper, softmax,
+ * multinomial): out_idx[r] ~ softmax(logits[r] / temperature) restricted to the top_k largest logits (ties kept) and then to
+ * the smallest set of largest probabilities whose mass reaches top_p; the draw is the inverse CDF at u[r] in [0, 1) (the
+ * caller's RNG stream).  temperature > 0, 0 < top_p <= 1; top_k <= 0 or > vocab disables the top-k filter, which is only
+ * supported for vocab <= 1024 (effective top_k <= 1024, else LVQ_EUNSUPPORTED). */
+int lvq_sample_rows(const float *logits, int64_t rows, int vocab, float temperature, int top_k, float top_p, const float *u,
+                    int64_t *out_idx, lvq_stream_t stream);
 int lvq_swiglu(const float *gate_up, int64_t rows, int inter, lvq_bf16 *out_hi, lvq_bf16 *out_lo, lvq_stream_t stream);
 /* sum over rows with labels[row] >= 0 of (logsumexp(logits[row]) - logits[row, label]) and their count:
  * loss = loss_sum_cnt[0] / loss_sum_cnt[1] (transformers causal-LM loss; labels already shifted by the

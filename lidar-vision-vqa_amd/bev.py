@@ -27,19 +27,31 @@ from .lidar import workspace
 # --------------------------------------------------------------------------------------------------
 # f2: on-disk BEV features
 # --------------------------------------------------------------------------------------------------
+def _npy_files(root: str):
+    """Every `*.npy` below `root`, depth first, directories and files in name order (os.walk; deterministic on any filesystem)."""
+    for base, dirs, files in os.walk(root):
+        dirs.sort()
+        for name in sorted(files):
+            if name.endswith(".npy"):
+                yield os.path.join(base, name)
+
+
 def collect_feature_tokens(feature_dirs: List[str]) -> Dict[str, str]:
-    """sample_token (file stem) -> path, over `**/*.npy` below every root, first occurrence wins; a missing root is
-    reported by rank 0 and skipped (training/data/utils.py:24-49)."""
-    token2path: Dict[str, str] = {}
+    """Index of the reference's on-disk BEV store (training/data/utils.py:24-49): sample_token = file stem -> path over every
+    `.npy` below the given roots (the writer puts them in split sub-folders, precompute_bev_features.py:391-395).  A token found
+    under several roots resolves to the EARLIEST root in `feature_dirs`; inside one root the first hit in name order wins
+    (the reference takes glob order there, which the filesystem decides).  Roots that do not exist are skipped with one
+    notice per job (rank 0)."""
+    index: Dict[str, str] = {}
+    absent = [d for d in feature_dirs if not os.path.isdir(d)]
+    if absent and os.environ.get("RANK", "0") == "0":
+        print("[bev] feature roots not found, skipped: " + ", ".join(map(str, absent)))
     for root in feature_dirs:
-        r = Path(root)
-        if not r.is_dir():
-            if int(os.environ.get("RANK", "0")) == 0:
-                print(f"[warn] feature root missing: {root}")
+        if root in absent:
             continue
-        for npy in r.glob("**/*.npy"):
-            token2path.setdefault(npy.stem, str(npy))
-    return token2path
+        for path in _npy_files(str(root)):
+            index.setdefault(os.path.splitext(os.path.basename(path))[0], path)
+    return index
 
 
 def save_bev_feature(path, bev) -> None:

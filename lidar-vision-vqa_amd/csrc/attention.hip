@@ -522,8 +522,12 @@ __device__ __forceinline__ void lds_tr_wait4(bf16x4 &a, bf16x4 &b, bf16x4 &c, bf
     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
 
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
+// QS = 1 ("mixed" precision): Q arrives as hi + lo and every score is K . (Q_hi + Q_lo) -- two MFMAs per K fragment on
+// the same accumulator -- while K, V and P stay plain bf16.  Rounding Q is the same perturbation for every key of a row, so it
+// does not average out over the stream the way the per-key roundings of K, V and P do (tools/precision_study.py: 2.8e-3 of the
+// 1e-3 budget at 262 144 keys); splitting it costs 4 of 12 MFMAs per 32-key block and 16 VGPRs, nothing in LDS or HBM.
+template <int NW, int QS, int WPS = 3>
+__global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
     constexpr int DH = 64, KROW = 64, CH = 8, NT = NW * 64;
     constexpr int NLD = (KVB * CH + NT - 1) / NT;
     constexpr int TILE_E = 2 * KVB * KROW;                     // K + V of one stage (bf16 elements)
@@ -543,15 +547,30 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     const float cexp0 = a.scale * 1.4426950408889634f;
 
     // Q^T fragments, pre-multiplied by scale * log2(e): lane supplies Q[qi][16 ks + 8 hi .. +7]
-    bf16x8 qf[4];
+    bf16x8 qf[4], qfl[QS ? 4 : 1];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (qi < a.Nq) v = *reinterpret_cast<const uint4 *>(a.q + (int64_t)b * a.q_bs + (int64_t)qi * a.ldq + (int64_t)h * a.q_hs + 16 * ks + 8 * hi);
-        uint32_t *w = reinterpret_cast<uint32_t *>(&v);
+        uint4 v = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+        const int64_t qo = (int64_t)b * a.q_bs + (int64_t)qi * a.ldq + (int64_t)h * a.q_hs + 16 * ks + 8 * hi;
+        if (qi < a.Nq) {
+            v = *reinterpret_cast<const uint4 *>(a.q + qo);
+            if (QS) vl = *reinterpret_cast<const uint4 *>(a.ql + qo);
+        }
+        uint32_t *w = reinterpret_cast<uint32_t *>(&v), *wl = reinterpret_cast<uint32_t *>(&vl);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) w[e] = pack_bf16(__uint_as_float(w[e] << 16) * cexp0, __uint_as_float(w[e] & 0xffff0000u) * cexp0);
+        for (int e = 0; e < 4; ++e) {
+            if (QS) {           // (hi + lo) * c in fp32, split again: hi' = bf16(x), lo' = bf16(x - hi')
+                const float x0 = (__uint_as_float(w[e] << 16) + __uint_as_float(wl[e] << 16)) * cexp0;
+                const float x1 = (__uint_as_float(w[e] & 0xffff0000u) + __uint_as_float(wl[e] & 0xffff0000u)) * cexp0;
+                const uint32_t hb = pack_bf16(x0, x1);
+                w[e] = hb;
+                wl[e] = pack_bf16(x0 - __uint_as_float(hb << 16), x1 - __uint_as_float(hb & 0xffff0000u));
+            } else {
+                w[e] = pack_bf16(__uint_as_float(w[e] << 16) * cexp0, __uint_as_float(w[e] & 0xffff0000u) * cexp0);
+            }
+        }
         qf[ks] = *reinterpret_cast<bf16x8 *>(&v);
+        if (QS) qfl[ks] = *reinterpret_cast<bf16x8 *>(&vl);
     }
     f32x16 o[2];
 #pragma unroll
@@ -623,6 +642,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + (kb * 32 + l31) * KROW + (((2 * ks + hi) ^ fk) << 3));
                 sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
+                if (QS) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[ks], sc[kb], 0, 0, 0);
             }
         }
     };
@@ -689,6 +709,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + (kb * 32 + l31) * KROW + (((2 * ks + hi) ^ fk) << 3));
                 sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
+                if (QS) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[ks], sc, 0, 0, 0);
             }
             // rows rb + {0, 8} (step 0) and rb + {16, 24} (step 1) of this 32-key block: byte immediates (32 kb + 8 j) * 128
             bf16x4 a00, a01, a10, a11, b00, b01, b10, b11;
@@ -840,8 +861,14 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int i4 = 0; i4 < 4; ++i4) {
-            const uint2 hv = make_uint2(pack_bf16(o[d][4 * i4] * inv, o[d][4 * i4 + 1] * inv), pack_bf16(o[d][4 * i4 + 2] * inv, o[d][4 * i4 + 3] * inv));
+            const float y0 = o[d][4 * i4] * inv, y1 = o[d][4 * i4 + 1] * inv, y2 = o[d][4 * i4 + 2] * inv, y3 = o[d][4 * i4 + 3] * inv;
+            const uint2 hv = make_uint2(pack_bf16(y0, y1), pack_bf16(y2, y3));
             *reinterpret_cast<uint2 *>(dst + 32 * d + 8 * i4 + 4 * hi) = hv;
+            if (a.ol) {
+                const uint2 lv = make_uint2(pack_bf16(y0 - __uint_as_float(hv.x << 16), y1 - __uint_as_float(hv.x & 0xffff0000u)),
+                                            pack_bf16(y2 - __uint_as_float(hv.y << 16), y3 - __uint_as_float(hv.y & 0xffff0000u)));
+                *reinterpret_cast<uint2 *>(a.ol + (dst - a.o) + 32 * d + 8 * i4 + 4 * hi) = lv;
+            }
         }
 }
 
@@ -892,7 +919,7 @@ __global__ void __launch_bounds__(256) k_attn_combine(AttnArgs a) {
 // launch geometry shared by lvq_attention_workspace_bytes and lvq_attention_bf16
 struct AttnPlan { int qt, nw, nqt, nsplit, k32; };
 // k_attn32 geometry (0 = not applicable): 32 queries per wave, 4 or 6 waves, at most 1/8 of the query slots padding
-int plan_k32_waves(int nq, int nkv, int dh, bool split) {
+int plan_k32_waves(int nq, int nkv, int dh, bool split) {      // split = K / V carry lo parts (full bf16x3): not this kernel
     if (split || dh != 64 || nkv < 4096 || (nkv % KVB) != 0 || getenv("LVQ_ATTN_NO32") != nullptr) return 0;
     const int force = getenv("LVQ_ATTN32_NW") ? atoi(getenv("LVQ_ATTN32_NW")) : 0;
     for (int nw : {4, 6}) {       // measured on 576 x 262144: 4 waves 2.29 ms, 6 waves 2.63, 3 waves 2.71 (three workgroups per CU at 4)
@@ -1082,6 +1109,8 @@ extern "C" size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, 
     return lvq_align(s) + lvq_align(p) + lvq_align(vt) + 1024;
 }
 
+extern "C" int lvq_attention_stream_ok(int nq, int nkv, int dh) { return plan_k32_waves(nq, nkv, dh, false) != 0; }
+
 extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k, const lvq_bf16 *k_lo,
                                   const lvq_bf16 *v, const lvq_bf16 *v_lo, const float *bias, int batch, int n_heads,
                                   int n_kv_heads, int nq, int nkv, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride,
@@ -1091,8 +1120,11 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
     if (batch <= 0 || n_heads <= 0 || n_kv_heads <= 0 || n_heads % n_kv_heads || nq < 0 || nkv <= 0 || dh <= 0 || !q || !k ||
         !v || !o)
         return LVQ_EINVAL;
-    const bool split = q_lo != nullptr;
-    if (split != (k_lo != nullptr) || split != (v_lo != nullptr)) return LVQ_EINVAL;
+    // precision modes: plain (no lo parts), bf16x3 (q, k, v all hi + lo), "mixed" stream form (q hi + lo, k / v plain: the
+    // long-stream kernel k_attn32<., 1> only -- lvq_attention_stream_ok says whether a shape takes it)
+    const bool split = k_lo != nullptr;
+    const bool qsplit = q_lo != nullptr && !split;
+    if (split != (v_lo != nullptr) || (split && !q_lo)) return LVQ_EINVAL;
     if (nq == 0) return LVQ_OK;
     if ((dh & 7) || (ldq & 7) || (ldk & 7) || (ldv & 7) || (q_hstride & 7) || (k_hstride & 7) || (v_hstride & 7) ||
         (q_bstride & 7) || (k_bstride & 7) || (v_bstride & 7) || (ldo & 3) || (o_hstride & 3) || (o_bstride & 3))
@@ -1112,7 +1144,8 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
         a.v_bs = v_bstride; a.ldv = ldv; a.v_hs = v_hstride; a.o_bs = o_bstride; a.ldo = ldo; a.o_hs = o_hstride;
         a.scale = scale; a.causal = causal; a.o = o; a.ol = o_lo;
         const int dhp = (dh + 31) / 32 * 32;
-        const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, split, bias == nullptr && !causal && o_lo == nullptr);
+        const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, split, bias == nullptr && !causal && (o_lo == nullptr || qsplit));
+        if (qsplit && !pl.k32) return LVQ_EUNSUPPORTED;
         a.nsplit = pl.nsplit; a.nqt = pl.nqt; a.part = nullptr;
         if (pl.nsplit > 1) {
             LvqArena arena(ws, ws_bytes);
@@ -1124,8 +1157,15 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
             const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
             const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;       // groups padded to the 8 XCDs (see the kernel's id mapping)
             if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
-            if (pl.k32 == 6)      hipLaunchKernelGGL(k_attn32<6>, dim3((unsigned)nwg), dim3(384), lds, st, a);
-            else                  hipLaunchKernelGGL(k_attn32<4>, dim3((unsigned)nwg), dim3(256), lds, st, a);
+            if (qsplit) {
+                const bool occ2 = getenv("LVQ_ATTN_QS_OCC2") != nullptr;      // experiment knob (256-VGPR build, 2 waves per SIMD)
+                if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 1>), dim3((unsigned)nwg), dim3(384), lds, st, a);
+                else if (occ2)    hipLaunchKernelGGL((k_attn32<4, 1, 2>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+                else              hipLaunchKernelGGL((k_attn32<4, 1>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+            } else {
+                if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 0>), dim3((unsigned)nwg), dim3(384), lds, st, a);
+                else              hipLaunchKernelGGL((k_attn32<4, 0>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+            }
             if (a.nsplit > 1) {
                 const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
                 hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
@@ -1149,7 +1189,7 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
         }
     }
     // ---- split path for large head dims: S = Q K^T (GEMM) -> row softmax -> O = P V (GEMM on V^T) ----
-    if (n_heads != n_kv_heads) return LVQ_EUNSUPPORTED;
+    if (n_heads != n_kv_heads || qsplit) return LVQ_EUNSUPPORTED;
     const int64_t nkp = (nkv + 7) / 8 * 8;
     const int ns = split ? 2 : 1;
     LvqArena arena(ws, ws_bytes);

@@ -432,6 +432,147 @@ __global__ void __launch_bounds__(256) k_cross_entropy(const float *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Sampling step of `generate(do_sample=True)` as transformers runs it for the reference's default call
+// (inference_engine.py:236-240, 283-296: temperature 0.7, top_k 50, top_p 0.9): TemperatureLogitsWarper ->
+// TopKLogitsWarper -> TopPLogitsWarper -> softmax -> one multinomial draw per row.
+//   * top-k keeps every logit >= the k-th largest (ties stay, as `scores < topk(scores, k)[0][..., -1]` removes only smaller
+//     ones): the threshold is found by a 4-pass radix select on the order-preserving uint image of the floats (no sort of the
+//     vocabulary), the survivors (<= SAMPLE_CAP) are collected into LDS and bitonic-sorted descending (ties: lower id first);
+//   * top-p keeps token j iff the probability mass ranked strictly before it is < top_p (the descending-order statement of
+//     `cumsum(softmax(sorted ascending)) <= 1 - top_p` is removed; at least one token stays);
+//   * the draw is the inverse CDF at the caller's uniform u in [0, 1) over the kept, renormalised probabilities.
+// One 1024-thread workgroup per row; the logits row is read 5 times from L2 (608 KB at Qwen2.5's vocabulary).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SAMPLE_NT = 1024;
+constexpr int SAMPLE_CAP = 2048;           // candidates held in LDS (top_k <= 1024 plus ties)
+
+__device__ __forceinline__ uint32_t f32_order_key(float x) {
+    const uint32_t b = __float_as_uint(x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);      // ascending uint order == ascending float order
+}
+
+__global__ void __launch_bounds__(SAMPLE_NT) k_sample_rows(const float *__restrict__ logits, int vocab, float inv_temp, int top_k, float top_p,
+                                                          const float *__restrict__ u, int64_t *__restrict__ out) {
+    __shared__ uint32_t hist[256];
+    __shared__ float c_val[SAMPLE_CAP];
+    __shared__ int c_idx[SAMPLE_CAP];
+    __shared__ float wsum[SAMPLE_NT / 64];
+    __shared__ uint32_t sh_prefix, sh_mask;
+    __shared__ int sh_remaining, sh_count, sh_keep;
+    __shared__ float sh_total;
+    const int tid = threadIdx.x;
+    const float *x = logits + (int64_t)blockIdx.x * vocab;
+    // ---- radix select: key of the k-th largest element ----
+    if (tid == 0) { sh_prefix = 0u; sh_mask = 0u; sh_remaining = top_k; sh_count = 0; }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const uint32_t prefix = sh_prefix, mask = sh_mask;
+        for (int i = tid; i < vocab; i += SAMPLE_NT) {
+            const uint32_t k = f32_order_key(x[i]);
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {                                     // walk the digits from the top until `remaining` elements are covered
+            int rem = sh_remaining, d = 255;
+            for (; d > 0; --d) {
+                const int c = (int)hist[d];
+                if (c >= rem) break;
+                rem -= c;
+            }
+            sh_remaining = rem;
+            sh_prefix = prefix | ((uint32_t)d << shift);
+            sh_mask = mask | (255u << shift);
+        }
+        __syncthreads();
+    }
+    const uint32_t kth = sh_prefix;                         // every element with key >= kth survives top-k
+    // ---- collect the survivors ----
+    for (int i = tid; i < SAMPLE_CAP; i += SAMPLE_NT) { c_val[i] = -INFINITY; c_idx[i] = 0x7fffffff; }
+    __syncthreads();
+    for (int i = tid; i < vocab; i += SAMPLE_NT) {
+        const float v = x[i];
+        if (f32_order_key(v) >= kth) {
+            const int q = atomicAdd(&sh_count, 1);
+            if (q < SAMPLE_CAP) { c_val[q] = v; c_idx[q] = i; }
+        }
+    }
+    __syncthreads();
+    const int n = sh_count < SAMPLE_CAP ? sh_count : SAMPLE_CAP;
+    // ---- bitonic sort, descending by value, ascending id among equals ----
+    for (int size = 2; size <= SAMPLE_CAP; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < SAMPLE_CAP / 2; t += SAMPLE_NT) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool desc = (lo & size) == 0;
+                const float a = c_val[lo], b = c_val[hi];
+                const int ia = c_idx[lo], ib = c_idx[hi];
+                const bool a_first = a > b || (a == b && ia < ib);      // a belongs before b in the final order
+                if (a_first != desc) { c_val[lo] = b; c_val[hi] = a; c_idx[lo] = ib; c_idx[hi] = ia; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- softmax numerators (temperature applied here: order is unchanged by a positive scale) and their prefix sums ----
+    const float top = c_val[0];
+    float p0 = 0.f, p1 = 0.f;
+    {
+        const int j = 2 * tid;
+        if (j < n) p0 = __expf((c_val[j] - top) * inv_temp);
+        if (j + 1 < n) p1 = __expf((c_val[j + 1] - top) * inv_temp);
+    }
+    float incl = p0 + p1;
+    const int lane = tid & 63, wid = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    float base = 0.f, total = 0.f;
+    for (int w = 0; w < SAMPLE_NT / 64; ++w) {
+        const float t = wsum[w];
+        if (w < wid) base += t;
+        total += t;
+    }
+    const float ex0 = base + incl - (p0 + p1), ex1 = ex0 + p0;    // mass ranked strictly before elements 2 tid and 2 tid + 1
+    __syncthreads();
+    // ---- top-p: keep j iff (mass before j) / total < top_p; the kept set is a prefix of the sorted list ----
+    if (tid == 0) sh_keep = 1;
+    __syncthreads();
+    {
+        const int j = 2 * tid;
+        const float cut = top_p * total;
+        int last = -1;
+        if (j < n && ex0 < cut) last = j;
+        if (j + 1 < n && ex1 < cut) last = j + 1;
+        if (last >= 0) atomicMax(&sh_keep, last + 1);
+    }
+    __syncthreads();
+    const int keep = sh_keep;
+    // kept mass = exclusive prefix at `keep` (or the total)
+    if (2 * tid == keep) sh_total = ex0;
+    if (2 * tid + 1 == keep) sh_total = ex1;
+    if (tid == 0 && keep >= n) sh_total = total;
+    __syncthreads();
+    // ---- inverse CDF: the first kept j whose inclusive mass exceeds u * kept mass ----
+    const float target = u[blockIdx.x] * sh_total;
+    if (tid == 0) sh_count = keep - 1;                      // fallback (u * mass rounding up to the whole mass)
+    __syncthreads();
+    {
+        const int j = 2 * tid;
+        if (j < keep && ex0 + p0 > target) atomicMin(&sh_count, j);
+        else if (j + 1 < keep && ex1 + p1 > target) atomicMin(&sh_count, j + 1);
+    }
+    __syncthreads();
+    if (tid == 0) out[blockIdx.x] = (int64_t)c_idx[sh_count];
+}
+
 }  // namespace
 
 extern "C" int lvq_layernorm(const float *x, const float *add, int add_rows, int add_group, const float *gamma,
@@ -532,6 +673,18 @@ extern "C" int lvq_rope_inplace_at(lvq_bf16 *x, lvq_bf16 *x_lo, int64_t rows, in
     const int64_t n = rows * n_heads * (dh / 2);
     hipLaunchKernelGGL(k_rope, dim3((unsigned)lvq_cdiv(n, 256)), dim3(256), 0, lvq_s(stream), x, x_lo, rows, seq_len, n_heads,
                        dh, ld, theta, pos0);
+    return lvq_launch_status();
+}
+
+extern "C" int lvq_sample_rows(const float *logits, int64_t rows, int vocab, float temperature, int top_k, float top_p, const float *u,
+                               int64_t *out_idx, lvq_stream_t stream) {
+    if (rows < 0 || vocab <= 0 || !(temperature > 0.f) || !(top_p > 0.f) || top_p > 1.f) return LVQ_EINVAL;
+    if (rows == 0) return LVQ_OK;
+    if (!logits || !u || !out_idx) return LVQ_EINVAL;
+    if (top_k <= 0 || top_k > vocab) top_k = vocab;         // transformers: top_k = 0 / None disables the filter
+    if (top_k > 1024 || rows > 0x7fffffff) return LVQ_EUNSUPPORTED;
+    hipLaunchKernelGGL(k_sample_rows, dim3((unsigned)rows), dim3(SAMPLE_NT), 0, lvq_s(stream), logits, vocab, 1.0f / temperature, top_k, top_p, u,
+                       out_idx);
     return lvq_launch_status();
 }
 

@@ -1196,7 +1196,10 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
                              int batch, int64_t a_bs, int64_t w_bs, int64_t c_bs, float *c_f32, lvq_bf16 *c_bf16,
                              lvq_bf16 *c_lo, lvq_stream_t stream) {
     if (m < 0 || n <= 0 || k <= 0 || batch <= 0 || !a || !w || (!c_f32 && !c_bf16)) return LVQ_EINVAL;
-    if ((a_lo == nullptr) != (w_lo == nullptr)) return LVQ_EINVAL;
+    // operand forms: plain (no lo parts), bf16x3 (a and w as hi + lo: hi*hi + hi*lo + lo*hi), and "x2w" (a plain, w hi + lo:
+    // a*w_hi + a*w_lo) -- the K|V projection of the "mixed" mode, where the per-row rounding of A averages out over the key
+    // stream but the rounding of W is common to every key
+    if (a_lo != nullptr && w_lo == nullptr) return LVQ_EINVAL;
     if (c_lo && !c_bf16) return LVQ_EINVAL;
     if (rowtab && rowtab_rows <= 0) return LVQ_EINVAL;
     if (m == 0) return LVQ_OK;
@@ -1204,13 +1207,13 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
     if ((k & 7) || (lda & 7) || (ldw & 7) || (a_bs & 7) || (w_bs & 7) || lda < k || ldw < k || ldc < n)
         return LVQ_EUNSUPPORTED;
     if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)a_lo | (uintptr_t)w_lo) & 15) return LVQ_EUNSUPPORTED;
-    if (m <= 8 && batch == 1 && n >= 64 && getenv("LVQ_GEMM_NO_GEMV") == nullptr) {          // skinny M: stream W once (k_gemv)
+    if (m <= 8 && batch == 1 && n >= 64 && (a_lo != nullptr || w_lo == nullptr) && getenv("LVQ_GEMM_NO_GEMV") == nullptr) {   // skinny M: stream W once (k_gemv)
         launch_gemv<0>(a_lo != nullptr, lvq_s(stream), a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, (flags & LVQ_GEMM_GELU) != 0,
                            (int)m, n, k, lda, ldw, ldc, c_f32, c_bf16, c_lo, nullptr, nullptr, 0.f);
         return lvq_launch_status();
     }
     GemmArgs g;
-    g.nseg = a_lo ? 3 : 1;
+    g.nseg = a_lo ? 3 : (w_lo ? 2 : 1);
     g.a[0] = a; g.w[0] = w;
     g.a[1] = a; g.w[1] = w_lo;
     g.a[2] = a_lo; g.w[2] = w;
@@ -1312,7 +1315,7 @@ extern "C" int lvq_gemm_ln_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const l
         return LVQ_EUNSUPPORTED;
     if (lvq_cdiv(m, 64) > 0x7fffffff) return LVQ_EUNSUPPORTED;
     GemmLnArgs g;
-    g.nseg = a_lo ? 3 : 1;
+    g.nseg = a_lo ? 3 : (w_lo ? 2 : 1);
     g.a[0] = a; g.w[0] = w; g.a[1] = a; g.w[1] = w_lo; g.a[2] = a_lo; g.w[2] = w;
     g.bias = bias; g.gamma = gamma; g.beta = beta; g.post = post_add; g.post_rows = post_rows; g.eps = eps;
     g.M = m; g.N = n; g.K = k; g.lda = lda; g.ldw = ldw; g.y16 = y_bf16; g.y16lo = y_lo;

@@ -42,8 +42,17 @@ class _HipModule(nn.Module):
         object.__setattr__(self, "_wcache", {})
         self.precision: Optional[str] = None   # None -> ops.default_precision()
 
+    def _mode(self) -> str:
+        return self.precision or ops.default_precision()
+
     def _split(self) -> bool:
-        return (self.precision or ops.default_precision()) == "bf16x3"
+        """Operands travel as hi + lo (bf16x3, and mixed outside its plain key stream)."""
+        return self._mode() in ("bf16x3", "mixed")
+
+    def _stream_plain(self, nq: int, nkv: int, dh: int) -> bool:
+        """mixed mode, and the K/V side of this attention is a long key stream whose per-key roundings average out: x, K, V, P
+        stay plain bf16 there (ops docstring) while the weights and the query side keep their lo parts."""
+        return self._mode() == "mixed" and ops.attention_stream_ok(nq, nkv, dh)
 
     def _w(self, p: torch.Tensor, pad_k: int = 0) -> BF:
         """bf16 (hi[, lo]) copy of a weight matrix [N,K]; rebuilt when the parameter changes."""
@@ -106,7 +115,8 @@ class VATBlock(_HipModule):
         return y
 
     def project_kv(self, kv_bf: BF) -> BF:
-        """K|V projection of the cross-attention: [B*Nkv, d] -> [B*Nkv, 2d] (rows d..3d of in_proj)."""
+        """K|V projection of the cross-attention: [B*Nkv, d] -> [B*Nkv, 2d] (rows d..3d of in_proj).  A plain kv_bf under split
+        weights (mixed mode, long stream) gives plain K|V from a @ (w_hi + w_lo)."""
         d = self.d_model
         _, kvp = ops.linear(kv_bf, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(d, 3 * d),
                             tag="ca_kv_proj")
@@ -134,6 +144,8 @@ class VATBlock(_HipModule):
 
     def forward_tokens(self, q2: torch.Tensor, kv_bf: BF, B: int, nq: int, nkv: int) -> torch.Tensor:
         q2 = self._self_attn(q2, B, nq)
+        if kv_bf[1] is not None and self._stream_plain(nq, nkv, self.d_model // self.n_heads):
+            kv_bf = (kv_bf[0], None)                     # mixed mode: the key stream's own rounding averages out
         q2 = self._cross_attn(q2, self.project_kv(kv_bf), B, nq, nkv)
         return self._mlp(q2)
 
@@ -242,22 +254,21 @@ class VATLiDAR(_HipModule):
         split = self._split()
         t = ops.dwconv3x3_gelu(_f32(bev), self.refine[0].weight.detach().reshape(C, 9).contiguous(), self.refine[0].bias, split)
         pe = self._pe_table(H, W, bev.device)
+        return self._tokens_to_model(t, H, W, bev.device)
+
+    def _tokens_to_model(self, t: BF, H: int, W: int, dev) -> BF:
+        """conv tokens t [B*HW, C] -> BEV tokens x [B*HW, d] = LayerNorm(proj(t)) + positional table (vat_lidar.py:222-248).
+        In mixed mode with a long key stream x leaves plain (its rounding is independent per key) from split t and W_proj."""
+        pe = self._pe_table(H, W, dev)
+        C = t[0].shape[1]
+        blk = self.blocks[0]
+        plain_x = self._stream_plain(self.n_queries, H * W, blk.d_model // blk.n_heads)
         if ops.linear_ln_supported(self.d_model, C):
             # 1x1 conv + LayerNorm + positional table in one row-complete kernel: no fp32 [B*HW, d] round trip
             return ops.linear_ln(t, self._w(self.proj.weight), self.proj.bias, self.norm_tokens.weight, self.norm_tokens.bias,
-                                 self.norm_tokens.eps, post=pe, tag="bev_proj_ln")
+                                 self.norm_tokens.eps, post=pe, tag="bev_proj_ln", out_lo=not plain_x)
         x32, _ = ops.linear(t, self._w(self.proj.weight), self.proj.bias, out_f32=True)
-        _, x = ops.layernorm(x32, self.norm_tokens.weight, self.norm_tokens.bias, self.norm_tokens.eps, split, post=pe)
-        return x
-
-    def _tokens_to_model(self, t: BF, H: int, W: int, dev) -> BF:
-        pe = self._pe_table(H, W, dev)
-        C = t[0].shape[1]
-        if ops.linear_ln_supported(self.d_model, C):
-            return ops.linear_ln(t, self._w(self.proj.weight), self.proj.bias, self.norm_tokens.weight, self.norm_tokens.bias,
-                                 self.norm_tokens.eps, post=pe, tag="bev_proj_ln")
-        x32, _ = ops.linear(t, self._w(self.proj.weight), self.proj.bias, out_f32=True)
-        _, x = ops.layernorm(x32, self.norm_tokens.weight, self.norm_tokens.bias, self.norm_tokens.eps, self._split(), post=pe)
+        _, x = ops.layernorm(x32, self.norm_tokens.weight, self.norm_tokens.bias, self.norm_tokens.eps, self._split() and not plain_x, post=pe)
         return x
 
     def forward_pillars(self, pillar_features: torch.Tensor, coords_bzyx: torch.Tensor, n_live: Optional[torch.Tensor],

@@ -223,15 +223,21 @@ class StandInHead(_HipModule):
     @torch.no_grad()
     def generate(self, inputs_embeds: torch.Tensor, attention_mask: Optional[torch.Tensor] = None, max_new_tokens: int = 64,
                  do_sample: bool = False, num_beams: int = 1, pad_token_id: Optional[int] = None,
-                 eos_token_id: Optional[int] = None, output_scores: bool = False, **unused):
-        """`base_model.generate(inputs_embeds=, attention_mask=, max_new_tokens=, do_sample=False, num_beams=1, pad_token_id=,
-        eos_token_id=)` as inference_engine.py:283-296 calls it: greedy decoding with a per-layer KV cache.  Returns the NEW
-        token ids [B, n] (what transformers returns when only inputs_embeds is given); with output_scores=True also the
-        per-step logits [B, n, V].  Sampling / beam search are not built (the reference's defaults do_sample=True,
-        temperature=0.7 draw from torch's RNG; pass do_sample=False for the deterministic path)."""
+                 eos_token_id: Optional[int] = None, output_scores: bool = False, temperature: float = 1.0, top_k: Optional[int] = 50,
+                 top_p: float = 1.0, generator: Optional[torch.Generator] = None, **unused):
+        """`base_model.generate(inputs_embeds=, attention_mask=, max_new_tokens=, temperature=, top_p=, top_k=, do_sample=,
+        num_beams=1, pad_token_id=, eos_token_id=)` as inference_engine.py:283-296 calls it, with a per-layer KV cache.
+        do_sample=False: greedy (first maximum).  do_sample=True (the reference's default, temperature 0.7 / top_k 50 / top_p 0.9):
+        every step draws from transformers' warped distribution (temperature -> top-k -> top-p) with lvq_sample_rows; the uniforms
+        come from torch's RNG (`generator` or torch.manual_seed), so runs are reproducible but -- like any two sampling
+        implementations -- not stream-identical to transformers' multinomial.  Returns the NEW token ids [B, n] (what transformers
+        returns when only inputs_embeds is given); with output_scores=True also the per-step raw logits [B, n, V].  Beam search
+        is not built."""
         self._guard(inputs_embeds)
-        if do_sample or num_beams != 1:
-            raise F.LvqError("StandInHead.generate implements greedy decoding only (do_sample=False, num_beams=1)")
+        if num_beams != 1:
+            raise F.LvqError("StandInHead.generate: beam search is not implemented (num_beams must be 1)")
+        if do_sample and not (temperature > 0.0 and 0.0 < top_p <= 1.0):
+            raise ValueError("temperature must be > 0 and top_p in (0, 1]")
         if attention_mask is not None and not bool((attention_mask == 1).all()):
             raise F.LvqError("StandInHead.generate expects an all-ones attention_mask (the reference builds exactly that)")
         c = self.cfg
@@ -257,7 +263,7 @@ class StandInHead(_HipModule):
         unfinished = torch.ones(B, dtype=torch.bool, device=dev)
         ids, scores = [], []
         for t in range(max_new_tokens):
-            nxt = ops.argmax_rows(step_logits)
+            nxt = ops.sample_rows(step_logits, temperature, top_k, top_p, generator) if do_sample else ops.argmax_rows(step_logits)
             if eos_token_id is not None:
                 nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
             ids.append(nxt)

@@ -1,7 +1,13 @@
 """Thin Python wrappers over the fusion-side C ABI (include/lvq.h): argument marshalling only.
 
-A "BF" value is a pair (hi, lo) of torch.bfloat16 tensors; lo is None in plain-bf16 mode and the
-residual x - hi in bf16x3 mode (see include/lvq.h "Precision modes").
+A "BF" value is a pair (hi, lo) of torch.bfloat16 tensors; lo is None for a plain-bf16 operand and the
+residual x - hi for a split one (see include/lvq.h "Precision modes").  Modes:
+  bf16    every operand plain (2^-9 operand rounding; fastest, ~3.5e-2 from the fp32 CPU reference on the bench workload)
+  bf16x3  every operand hi + lo, every product hi*hi + hi*lo + lo*hi (meets the 1e-3 bar everywhere; 2.7x slower)
+  mixed   bf16x3 everywhere EXCEPT the tensors whose rounding is independent per key of a long K/V stream and therefore
+          averages out in the softmax-weighted sum (BEV tokens x, K, V, P of VATLiDAR's cross-attention: 262 144 keys): those
+          stay plain.  Operands whose rounding is COMMON to all keys stay split: weights (W_proj, W_k|W_v), the conv tokens
+          (93 % of the cells hold the same constant) and the query side.  tools/precision_study.py measures each group.
 """
 from __future__ import annotations
 
@@ -14,7 +20,7 @@ from . import _ffi as F
 
 BF = Tuple[torch.Tensor, Optional[torch.Tensor]]
 
-PRECISIONS = ("bf16", "bf16x3")
+PRECISIONS = ("bf16", "bf16x3", "mixed")
 _default_precision = os.environ.get("LVQ_PRECISION", "bf16x3")
 assert _default_precision in PRECISIONS
 
@@ -112,11 +118,11 @@ def linear(a: BF, w: BF, bias: Optional[torch.Tensor] = None, *, gelu: bool = Fa
     m, k = ah.shape
     r0, r1 = w_rows if w_rows is not None else (0, wh.shape[0])
     n = r1 - r0
-    assert wh.shape[1] == k and (al is None) == (wl is None)
+    assert wh.shape[1] == k and (al is None or wl is not None)      # plain | bf16x3 | a plain, w split ("x2w")
     dev = ah.device
-    split = al is not None
+    split = wl is not None
     c32 = torch.empty((m, n), dtype=torch.float32, device=dev) if out_f32 else None
-    ch, cl = _bf_empty((m, n), dev, split) if out_bf else (None, None)
+    ch, cl = _bf_empty((m, n), dev, al is not None) if out_bf else (None, None)
     wo = r0 * k * 2  # byte offset of the weight row slice
     bo = r0 * 4
     import ctypes
@@ -142,12 +148,12 @@ def attention(q: BF, k: BF, v: BF, *, batch: int, n_heads: int, n_kv_heads: int,
     import ctypes
     qh, ql = q
     dev = qh.device
-    split = ql is not None
+    split = ql is not None                       # q split, k / v plain = the "mixed" stream form (lvq_attention_stream_ok shapes)
     oh, ol = _bf_empty((batch * nq, n_heads * dh), dev, split)
     L = F.lib()
     L.lvq_attention_workspace_bytes.restype = ctypes.c_size_t
     nbytes = L.lvq_attention_workspace_bytes(F.cint(batch), F.cint(n_heads), F.cint(nq), F.cint(nkv), F.cint(dh),
-                                             F.cint(3 if split else 1))
+                                             F.cint(3 if k[1] is not None else 1))
     key = (dev.index, "attn")
     ws = _ATT_WS.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -165,6 +171,11 @@ def attention(q: BF, k: BF, v: BF, *, batch: int, n_heads: int, n_kv_heads: int,
             F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
     F.check(rc, f"lvq_attention_bf16 (B={batch}, H={n_heads}, nq={nq}, nkv={nkv}, dh={dh})")
     return oh, ol
+
+
+def attention_stream_ok(nq: int, nkv: int, dh: int) -> bool:
+    """True when lvq_attention_bf16 takes (q split, k / v plain) for this shape: the long-stream kernel's shapes."""
+    return bool(F.lib().lvq_attention_stream_ok(F.cint(nq), F.cint(nkv), F.cint(dh)))
 
 
 def dwconv3x3_gelu(bev: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], split: bool) -> BF:
@@ -234,6 +245,19 @@ def argmax_rows(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def sample_rows(logits: torch.Tensor, temperature: float, top_k: int, top_p: float, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """[rows, vocab] fp32 -> [rows] int64 drawn like transformers' do_sample step (temperature -> top-k -> top-p -> multinomial,
+    lvq_sample_rows).  The uniforms come from torch's RNG on the logits' device (seedable through `generator` / torch.manual_seed)."""
+    F.require_cuda(logits)
+    rows, n = logits.shape
+    u = torch.rand((rows,), dtype=torch.float32, device=logits.device, generator=generator)
+    out = torch.empty((rows,), dtype=torch.int64, device=logits.device)
+    rc = F.lib().lvq_sample_rows(F.ptr(logits), F.i64(rows), F.cint(n), F.cfloat(temperature), F.cint(int(top_k or 0)), F.cfloat(top_p),
+                                 F.ptr(u), F.ptr(out), F.stream_ptr(logits.device))
+    F.check(rc, f"lvq_sample_rows (vocab={n}, top_k={top_k}: the top-k filter may only be disabled for vocab <= 1024)")
+    return out
+
+
 def swiglu(gate_up: torch.Tensor, split: bool) -> BF:
     rows, two_i = gate_up.shape
     hi, lo = _bf_empty((rows, two_i // 2), gate_up.device, split)
@@ -259,14 +283,15 @@ def linear_ln_supported(n: int, k: int) -> bool:
 
 
 def linear_ln(a: BF, w: BF, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: Optional[torch.Tensor], eps: float,
-              post: Optional[torch.Tensor] = None, tag: Optional[str] = None) -> BF:
-    """LayerNorm(a @ w.T + bias) * gamma + beta + post[row % rows] -> BF, no fp32 [M,N] intermediate (lvq_gemm_ln_bf16)."""
+              post: Optional[torch.Tensor] = None, tag: Optional[str] = None, out_lo: Optional[bool] = None) -> BF:
+    """LayerNorm(a @ w.T + bias) * gamma + beta + post[row % rows] -> BF, no fp32 [M,N] intermediate (lvq_gemm_ln_bf16).
+    out_lo=False: split operands, plain result (the "mixed" mode's BEV tokens)."""
     ah, al = a
     wh, wl = w
     m, k = ah.shape
     n = wh.shape[0]
     split = al is not None
-    yh, yl = _bf_empty((m, n), ah.device, split)
+    yh, yl = _bf_empty((m, n), ah.device, split if out_lo is None else (out_lo and split))
     with region(tag, ah.device):
         rc = F.lib().lvq_gemm_ln_bf16(F.ptr(ah), F.ptr(al), F.ptr(wh), F.ptr(wl), F.ptr(bias), F.ptr(gamma), F.ptr(beta), F.cfloat(eps),
                                       F.ptr(post), F.i64(post.shape[0] if post is not None else 0), F.i64(m), F.cint(n), F.cint(k),

@@ -429,3 +429,71 @@ def test_full_headline_shape_properties():
         assert (m.cross_attention(q, kv[:, kperm]) - full).abs().max().item() < 2e-2
         assert torch.equal(m.cross_attention(q[:, 1000:1512], kv), full[:, 1000:1512])
     assert bool(torch.isfinite(full).all())
+
+
+# ------------------------------------------------------------------------------------------------
+# "mixed" precision mode: plain bf16 on the long key stream, hi + lo everywhere else
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,k", [(300, 136, 72), (4096, 1536, 768), (65536, 1024, 128), (5, 256, 64)])
+def test_gemm_plain_a_split_w(m, n, k):
+    """lvq_gemm_bf16 with a plain and w = hi + lo (the mixed mode's K|V projection): a @ (w_hi + w_lo), i.e. exact in W."""
+    o = ops()
+    a = bf_round(torch.from_numpy(synth.randn((m, k), 81))).to(DEV)
+    w = torch.from_numpy(synth.randn((n, k), 82, 0.1)).to(DEV)
+    bias = torch.from_numpy(synth.randn((n,), 83)).to(DEV)
+    c32, cb = o.linear(o.cast(a, False), o.cast(w, True), bias, out_f32=True, out_bf=True)
+    assert cb[1] is None                                                 # plain result
+    ref = a.double().cpu() @ w.double().cpu().t() + bias.double().cpu()
+    scale = max(1.0, ref.abs().max().item())
+    assert (c32.double().cpu() - ref).abs().max().item() < 2e-4 * scale  # W to 2^-17: same bound as the bf16x3 product
+    plain, _ = o.linear(o.cast(a, False), o.cast(w, False), bias, out_f32=True)
+    assert (plain.double().cpu() - ref).abs().max().item() > 5 * (c32.double().cpu() - ref).abs().max().item()
+    assert (o.to_f32(cb).double().cpu() - ref).abs().max().item() < 1e-2 * scale
+
+
+@pytest.mark.parametrize("B,H,nq,nkv,occ2", [(1, 2, 576, 8192, False), (2, 3, 120, 4096, False), (1, 12, 576, 16384, False),
+                                             (1, 2, 576, 8192, True)])
+def test_attention_stream_q_split(B, H, nq, nkv, occ2, monkeypatch):
+    """lvq_attention_bf16 with q = hi + lo, k / v plain (k_attn32<., 1>): exact in Q, bf16 in K, V and P."""
+    if occ2:
+        monkeypatch.setenv("LVQ_ATTN_QS_OCC2", "1")
+    o = ops()
+    dh = 64
+    assert o.attention_stream_ok(nq, nkv, dh) and not o.attention_stream_ok(nq, 196, dh) and not o.attention_stream_ok(nq, nkv, 128)
+    q = torch.from_numpy(synth.randn((B, nq, H, dh), 91)).to(DEV) * 1.7
+    k = bf_round(torch.from_numpy(synth.randn((B, nkv, H, dh), 92))).to(DEV)
+    v = bf_round(torch.from_numpy(synth.randn((B, nkv, H, dh), 93))).to(DEV)
+    qb = o.cast(q.reshape(-1, H * dh), True)
+    kb, vb = (o.cast(t.reshape(-1, H * dh), False) for t in (k, v))
+    st = lambda n: (n * H * dh, H * dh, dh)
+    out = o.attention(qb, kb, vb, batch=B, n_heads=H, n_kv_heads=H, nq=nq, nkv=nkv, dh=dh, q_strides=st(nq), k_strides=st(nkv),
+                      v_strides=st(nkv), scale=1.0 / math.sqrt(dh))
+    assert out[1] is not None
+    got = o.to_f32(out).double().cpu().view(B, nq, H, dh)
+    qd, kd, vd = (t.double().cpu().transpose(1, 2) for t in (q, k, v))
+    p = torch.softmax(qd @ kd.transpose(-1, -2) / math.sqrt(dh), -1)
+    ref = (p @ vd).transpose(1, 2)
+    err = (got - ref).abs().max().item()
+    # what is left is P's bf16 rounding, independent per key: ~2^-9 |v| sqrt(sum p^2)
+    bound = 8.0 * 2.0 ** -9 * float(torch.sqrt((p ** 2).sum(-1)).max()) * float(vd.abs().max())
+    assert err < bound, (err, bound)
+    plain = o.attention((qb[0], None), kb, vb, batch=B, n_heads=H, n_kv_heads=H, nq=nq, nkv=nkv, dh=dh, q_strides=st(nq),
+                        k_strides=st(nkv), v_strides=st(nkv), scale=1.0 / math.sqrt(dh))
+    err_plain = (o.to_f32(plain).double().cpu().view(B, nq, H, dh) - ref).abs().max().item()
+    assert err_plain > 2.0 * err, (err_plain, err)                       # rounding Q is the error that does not average out
+    with pytest.raises(Exception):                                       # the mixed operand form exists for stream shapes only
+        o.attention(qb, (kb[0][:196 * B], None), (vb[0][:196 * B], None), batch=B, n_heads=H, n_kv_heads=H, nq=nq, nkv=196, dh=dh,
+                    q_strides=st(nq), k_strides=st(196), v_strides=st(196), scale=1.0 / math.sqrt(dh))
+
+
+@pytest.mark.parametrize("name", ["d768_h12", "c128_d256", "tiny"])
+def test_vat_lidar_golden_mixed(name):
+    """mixed mode on module goldens: where the key stream is short (tiny / 50 x 50 grids: the long-stream kernel does not apply)
+    it IS bf16x3; the 1e-3 bar holds either way."""
+    c = cases.VAT_LIDAR_CASES[name]
+    m = fusion().VATLiDAR(c["c_in"], c["d"], c["nq"], c["L"], c["h"]).to(DEV).eval()
+    synth.load_seeded(m, c["seed"])
+    m.precision = "mixed"
+    with torch.no_grad():
+        out = m(dev(synth.randn((c["B"], c["c_in"], c["H"], c["W"]), c["seed"] + 1000)))
+    check_golden(out, golden("vat_lidar_" + name), "bf16x3")

@@ -129,7 +129,7 @@ def test_greedy_generate_vs_transformers(prec, tol):
                          eos_token_id=int(g["eos"]))
     assert np.array_equal(ids2.cpu().numpy(), g["ids_eos"])
     with pytest.raises(_ffi.LvqError):
-        base.generate(inputs_embeds=inp, do_sample=True)
+        base.generate(inputs_embeds=inp, num_beams=2)                      # beam search is not built
     x = torch.tensor([[1.0, 5.0, 5.0, -2.0], [-3.0, -3.0, -7.0, -3.0]], device=DEV)
     assert ops.argmax_rows(x).cpu().tolist() == [1, 0]                     # first maximum
     big = torch.randn(7, 151936, device=DEV)
@@ -233,3 +233,83 @@ def test_skinny_gemv_matches_tile_gemm(m, n, k, split, monkeypatch):
         scale = float(ref32.abs().max()) + 1e-6
         assert (got32 - ref32).abs().max().item() < 2e-5 * scale * max(1.0, k / 256)        # same products, different summation order
         assert (got16 - ref16).abs().max().item() < (2e-5 if split else 8e-3) * scale
+
+
+def _hf_warped_probs(row: torch.Tensor, temperature, top_k, top_p) -> torch.Tensor:
+    """The distribution transformers samples from: its own logits processors applied to one row (CPU)."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    s = row[None].clone()
+    ids = torch.zeros((1, 1), dtype=torch.long)
+    s = TemperatureLogitsWarper(temperature)(ids, s)
+    if top_k and top_k > 0:
+        s = TopKLogitsWarper(top_k=top_k)(ids, s)
+    if top_p < 1.0:
+        s = TopPLogitsWarper(top_p=top_p)(ids, s)
+    return torch.softmax(s, dim=-1)[0]
+
+
+@pytest.mark.parametrize("vocab,temperature,top_k,top_p", [(400, 0.7, 50, 0.9), (1000, 1.3, 7, 1.0), (300, 0.7, 0, 0.5), (64, 1.0, 64, 0.95),
+                                                           (5000, 0.25, 1000, 0.999)])
+def test_sample_rows_distribution(vocab, temperature, top_k, top_p):
+    """lvq_sample_rows draws from the distribution transformers' warpers define (the reference's default call: temperature 0.7,
+    top_k 50, top_p 0.9, inference_engine.py:236-240): support exactly inside the kept set, frequencies within 5 sigma of the
+    warped probabilities over 120 000 draws, and as close to them as torch.multinomial's own draws of the same size are."""
+    from lidar_vision_vqa_amd import ops
+    n = 120000
+    g = torch.Generator().manual_seed(vocab + top_k)
+    row = torch.randn(vocab, generator=g) * 2.0
+    p = _hf_warped_probs(row, temperature, top_k, top_p).double()
+    logits = row.to(DEV)[None].expand(n, vocab).contiguous()
+    gen = torch.Generator(device=DEV).manual_seed(1234)
+    ids = ops.sample_rows(logits, temperature, top_k, top_p, gen).cpu()
+    assert ids.dtype == torch.int64 and int(ids.min()) >= 0 and int(ids.max()) < vocab
+    freq = torch.bincount(ids, minlength=vocab).double() / n
+    assert bool((freq[p == 0] == 0).all()), "a token outside transformers' kept set was drawn"
+    sigma = torch.sqrt(p * (1 - p) / n)
+    assert float(((freq - p).abs() / (sigma + 1.0 / n)).max()) < 5.5
+    ref = torch.bincount(torch.multinomial(p.float(), n, replacement=True, generator=g), minlength=vocab).double() / n
+    tv_ours, tv_torch = 0.5 * float((freq - p).abs().sum()), 0.5 * float((ref - p).abs().sum())
+    assert tv_ours < 2.0 * tv_torch + 1e-3, (tv_ours, tv_torch)
+    # same seed -> same draws; u -> id is monotone in the rank order (inverse CDF)
+    assert torch.equal(ops.sample_rows(logits, temperature, top_k, top_p, torch.Generator(device=DEV).manual_seed(1234)).cpu(), ids)
+
+
+def test_sample_rows_edge_cases():
+    from lidar_vision_vqa_amd import ops, _ffi
+    # top_k = 1 is greedy; ties at the k-th value are all kept (transformers removes only scores < the k-th largest)
+    x = torch.randn(9, 151936, device=DEV)                             # Qwen2.5 vocabulary width
+    assert torch.equal(ops.sample_rows(x, 0.7, 1, 0.9), x.argmax(-1))
+    ids = ops.sample_rows(x, 0.7, 50, 0.9)
+    top50 = x.topk(50, dim=-1).indices
+    assert bool((ids[:, None] == top50).any(-1).all())
+    flat = torch.zeros(20000, 300, device=DEV)                          # every logit ties: top_k = 5 keeps all 300
+    ids = ops.sample_rows(flat, 1.0, 5, 1.0, torch.Generator(device=DEV).manual_seed(3)).cpu()
+    cnt = torch.bincount(ids, minlength=300)
+    assert int(cnt.min()) > 20 and int(cnt.max()) < 140
+    with pytest.raises(_ffi.LvqError):
+        ops.sample_rows(x, 0.7, 0, 0.9)                                 # top-k disabled on a 151 936-wide row: not supported
+    with pytest.raises(_ffi.LvqError):
+        ops.sample_rows(x, 0.0, 50, 0.9)
+
+
+def test_engine_default_call_samples():
+    """The reference's DEFAULT `engine.generate(question, bev)` (do_sample=True, temperature 0.7, top_k 50, top_p 0.9) runs on
+    the drop-in, is reproducible under a seeded generator, and collapses to the greedy answer at top_k = 1."""
+    from lidar_vision_vqa_amd import engine
+    hc = cases.HEAD_CASE
+    base, vl, va, vv = build(hc, "bf16x3")
+    tok = synth.DummyTokenizer(hc["vocab"])
+    eng = engine.InferenceEngine(dict(tokenizer=tok, base_model=base, vat_lidar=vl, device=torch.device(DEV), d_model=hc["d"],
+                                      config=dict(use_vision=False, prefix_scale=0.2)))
+    bev = synth.randn((16, 10, 10), hc["seed"] + 40)
+    q = "How many cars are ahead of the ego vehicle?"
+    a = eng.generate(q, bev, max_new_tokens=12, generator=torch.Generator(device=DEV).manual_seed(7))
+    b = eng.generate(q, bev, max_new_tokens=12, generator=torch.Generator(device=DEV).manual_seed(7))
+    assert isinstance(a, str) and a == b
+    outs = {eng.generate(q, bev, max_new_tokens=12, generator=torch.Generator(device=DEV).manual_seed(s)) for s in range(6)}
+    assert len(outs) > 1                                                # it does sample
+    greedy = eng.generate(q, bev, max_new_tokens=12, do_sample=False)
+    assert eng.generate(q, bev, max_new_tokens=12, top_k=1) == greedy
+    assert len(eng.generate_batch([q, q], [bev, bev], max_new_tokens=3)) == 2
+    with pytest.raises(Exception):
+        eng.generate(q, bev, num_beams=4)

@@ -29,10 +29,13 @@ from oracle import lidar_oracle as LO
 from oracle import vat_oracle as VO
 
 ACTIVE = set()
+F16 = set()          # tags rounded to fp16 (11-bit significand) instead of bf16 (8-bit)
 
 
 def r(tag: str, x: torch.Tensor) -> torch.Tensor:
-    """Round to bf16 (RNE) when the tag's group is active."""
+    """Round to bf16 (RNE) when the tag's group is active; to fp16 when the tag is in F16."""
+    if tag in F16:
+        return x.half().float()
     return x.bfloat16().float() if tag in ACTIVE else x
 
 
@@ -173,6 +176,11 @@ def main():
     for name, groups in MIXED_CANDIDATES.items():
         out, lt, dt = run(groups)
         print(f"{name:60s} fused err {(out - ref).abs().max().item():.3e}   lidar-token err {(lt - ref_lt).abs().max().item():.3e}", flush=True)
+    # scores in fp16 (Q and K rounded to 11 bits instead of 8; same MFMA rate): how much of the Q-side error is left?
+    F16.update(["lidar.ca.q", "lidar.ca.kv"])
+    out, lt, dt = run(["stream: BEV tokens x (A of K|V proj)", "stream: P (softmax numerators)"])
+    F16.clear()
+    print(f"{'x, P bf16; Q, K, V fp16; everything else exact':60s} fused err {(out - ref).abs().max().item():.3e}   lidar-token err {(lt - ref_lt).abs().max().item():.3e}", flush=True)
     out, lt, dt = run(list(GROUPS))
     print(f"{'everything bf16':60s} fused err {(out - ref).abs().max().item():.3e}   lidar-token err {(lt - ref_lt).abs().max().item():.3e}", flush=True)
 
