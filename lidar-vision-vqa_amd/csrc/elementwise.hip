@@ -445,6 +445,24 @@ __global__ void __launch_bounds__(256) k_cross_entropy(const float *__restrict__
 //   * the draw is the inverse CDF at the caller's uniform u in [0, 1) over the kept, renormalised probabilities.
 // One 1024-thread workgroup per row; the logits row is read 5 times from L2 (608 KB at Qwen2.5's vocabulary).
 // ---------------------------------------------------------------------------------------------------------
+// column sums of a row-major [rows, d] fp32 matrix in a FIXED order (the payload of the per-step all-reduce):
+// one workgroup per 64 columns, thread (r, c) walks rows r, r + 16, ... of column c, then the 16 partials are added in order
+__global__ void __launch_bounds__(1024) k_colsum(const float *__restrict__ x, int64_t rows, int d, float *__restrict__ out) {
+    __shared__ float part[16][64];
+    const int c = threadIdx.x & 63, r = threadIdx.x >> 6, col = blockIdx.x * 64 + c;
+    float acc = 0.f;
+    if (col < d)
+        for (int64_t i = r; i < rows; i += 16) acc += x[i * d + col];
+    part[r][c] = acc;
+    __syncthreads();
+    if (r == 0 && col < d) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += part[k][c];
+        out[col] = s;
+    }
+}
+
 constexpr int SAMPLE_NT = 1024;
 constexpr int SAMPLE_CAP = 2048;           // candidates held in LDS (top_k <= 1024 plus ties)
 
@@ -673,6 +691,12 @@ extern "C" int lvq_rope_inplace_at(lvq_bf16 *x, lvq_bf16 *x_lo, int64_t rows, in
     const int64_t n = rows * n_heads * (dh / 2);
     hipLaunchKernelGGL(k_rope, dim3((unsigned)lvq_cdiv(n, 256)), dim3(256), 0, lvq_s(stream), x, x_lo, rows, seq_len, n_heads,
                        dh, ld, theta, pos0);
+    return lvq_launch_status();
+}
+
+extern "C" int lvq_colsum(const float *x, int64_t rows, int d, float *out, lvq_stream_t stream) {
+    if (rows < 0 || d <= 0 || !out || (rows > 0 && !x)) return LVQ_EINVAL;
+    hipLaunchKernelGGL(k_colsum, dim3((unsigned)lvq_cdiv(d, 64)), dim3(1024), 0, lvq_s(stream), x, rows, d, out);
     return lvq_launch_status();
 }
 

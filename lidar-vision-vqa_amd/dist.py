@@ -69,8 +69,15 @@ def reduce_step(per_scene: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
     per_scene [S, n, d] (fused tokens, or answer logits once the head is attached).  After the call
     buf[:-1] / buf[-1] is the global per-scene mean.  Stream-ordered; returns buf."""
     S = per_scene.shape[0]
-    buf[:-1] = per_scene.sum(dim=(0, 1))
-    buf[-1] = float(S)
+    if per_scene.is_cuda:
+        from . import _ffi as F                      # HIP path: column sums in a fixed order (lvq_colsum), count slot by fill
+        x = per_scene.reshape(-1, per_scene.shape[-1])
+        F.require_cuda(x, buf)
+        F.check(F.lib().lvq_colsum(F.ptr(x), F.i64(x.shape[0]), F.cint(x.shape[1]), F.ptr(buf), F.stream_ptr(x.device)), "lvq_colsum")
+        buf[-1:].fill_(float(S))
+    else:                                            # gloo rehearsal on CPU tensors (tests/test_dist.py)
+        buf[:-1] = per_scene.sum(dim=(0, 1))
+        buf[-1] = float(S)
     if is_dist():
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf

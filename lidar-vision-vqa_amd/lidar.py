@@ -223,6 +223,14 @@ class _PFNParams(nn.Module):
         self.cin, self.cout = in_channels, out_channels
 
     def folded(self):
+        """(W, scale, shift) with the eval-mode BatchNorm folded into a per-channel affine.  Input-independent: computed once
+        per weights version (parameter / buffer storage + in-place version counters), not per forward."""
+        src = [self.linear.weight] + ([self.norm.weight, self.norm.bias, self.norm.running_mean, self.norm.running_var]
+                                      if self.use_norm else [self.linear.bias])
+        ver = tuple((t.data_ptr(), t._version, t.device) for t in src)
+        hit = getattr(self, "_folded_cache", None)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
         w = self.linear.weight.detach().float().contiguous()
         if self.use_norm:
             scale = self.norm.weight.detach().float() / torch.sqrt(self.norm.running_var.float() + self.norm.eps)
@@ -230,7 +238,9 @@ class _PFNParams(nn.Module):
         else:
             scale = torch.ones(self.cout, device=w.device)
             shift = self.linear.bias.detach().float()
-        return w, scale.contiguous(), shift.contiguous()
+        out = (w, scale.contiguous(), shift.contiguous())
+        object.__setattr__(self, "_folded_cache", (ver, out))
+        return out
 
 
 class _PFNStack(VFETemplate):
