@@ -211,6 +211,49 @@ int lvq_bf16_to_f32(const lvq_bf16 *hi, const lvq_bf16 *lo, int64_t n, float alp
  *   kernel, no workspace.  Larger dh (448, 1024: the reference's 2-head defaults) or dh % 16 == 8: split
  *   path (scores GEMM -> row softmax -> PV GEMM) using the workspace; needs n_heads == n_kv_heads. */
 size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, int nkv, int dh, int precision);
+/* =====================================================================================
+ * f1/f3  sparse BEV key stream of VATLiDAR (vat_lidar.py:212-248 + vat_blocks.py:42; csrc/bev_tiles.hip).
+ * A BEV cell with an empty 3x3 neighbourhood gives a token -- and K|V rows -- that depend on the weights only.  The stream runs
+ * tile-major over 8 x 8-cell tiles (64 keys each; key order is free under softmax): CLEAN tiles (no pillar in the 10 x 10 halo)
+ * are read from a per-model K|V table that the caller builds once per weights version by running these same entry points on an
+ * empty scene with force_all = 1 (bit-identical rows by construction), LIVE tiles are computed per scene.
+ * ===================================================================================== */
+/* PointPillarScatter (pointpillar_scatter.py:14-37) as an index map instead of a canvas: idx_map[b, y, x] = pillar row or -1.
+ * Rows >= *n_voxels_dev (if given) are ignored. */
+int lvq_pillar_index_map(const int32_t *coords_bzyx, int64_t m_cap, const int32_t *n_voxels_dev, int batch, int ny, int nx,
+                         int32_t *idx_map, lvq_stream_t stream);
+/* Tile bookkeeping.  ny, nx multiples of 8; nt = (ny/8)(nx/8) tiles per scene.
+ *   live_list [batch * nt]   code t * batch + s of the k-th live tile, in (tile, scene) order
+ *   tile_src  [batch * nt]   per (scene s, tile t) at s * nt + t: 64 k (first row of the tile among the live rows) or ~(64 t)
+ *                            (first row of the tile in the table) when the tile is clean
+ *   counts    [2]            live tiles, live rows (= 64 x)
+ * force_all != 0 marks every tile live (table build; dense comparator). */
+size_t lvq_bev_tiles_workspace_bytes(int batch, int ny, int nx);
+int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, int force_all, int32_t *live_list, int32_t *tile_src,
+                  int32_t *counts, void *ws, size_t ws_bytes, lvq_stream_t stream);
+/* Tokens of the live tiles, fused: pillar gather + depthwise 3x3 + GELU (refine, vat_lidar.py:212-221; tap order and fmaf chain of
+ * lvq_dwconv3x3_gelu) -> 1x1 conv (proj) -> LayerNorm (norm_tokens) -> + positional table (pe_tiled [ny*nx, n] fp32 in tile-major
+ * row order).  x [cap_tiles * 64, n] row 64 k + cell = cell (8 y + x inside the tile) of the k-th live tile.  w_lo != NULL: conv
+ * tokens and W as hi + lo (three products); x_lo != NULL additionally stores the lo half of x.  c_in = 64, n in {256, 512, 768,
+ * 1024} (else LVQ_EUNSUPPORTED: use lvq_pillar_dwconv3x3_gelu + lvq_gemm_ln_bf16). */
+int lvq_bev_tile_tokens(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *counts,
+                        int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9, const lvq_bf16 *w,
+                        const lvq_bf16 *w_lo, const float *bias, const float *gamma, const float *beta, float eps, const float *pe_tiled,
+                        int n, lvq_bf16 *x, lvq_bf16 *x_lo, lvq_stream_t stream);
+/* c[0 .. *m_rows_dev) = a @ w^T + bias over the live rows only (the row count stays on the device); m_cap, n multiples of 256,
+ * k of 64.  Operand forms as lvq_gemm_bf16 (plain | a plain, w hi + lo | both hi + lo). */
+int lvq_gemm_bf16_live_rows(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,
+                            int64_t m_cap, const int32_t *m_rows_dev, int n, int k, int64_t lda, int64_t ldw, int64_t ldc,
+                            lvq_bf16 *c_bf16, lvq_bf16 *c_lo, lvq_stream_t stream);
+/* softmax(q K^T * scale) V over the tiled stream: batch b reads tile t from row tile_src[b * n_tiles + t] of k_live / v_live when
+ * that is >= 0, from row ~tile_src of k_table / v_table otherwise.  Shapes of lvq_attention_stream_ok(nq, 64 * n_tiles, 64) only;
+ * q plain or hi + lo (mixed mode), K / V plain.  Workspace: lvq_attention_workspace_bytes(batch, n_heads, nq, 64 * n_tiles, 64, 1). */
+int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_live, const lvq_bf16 *v_live,
+                             const lvq_bf16 *k_table, const lvq_bf16 *v_table, const int32_t *tile_src, int batch, int n_heads, int nq,
+                             int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv, int64_t kv_hstride,
+                             int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o, lvq_bf16 *o_lo, void *ws,
+                             size_t ws_bytes, lvq_stream_t stream);
+
 /* 1 when the long-stream kernel takes (nq, nkv, dh) without bias / mask: head_dim 64, nkv >= 4096 and a multiple of 64, query
  * count with at most 1/8 padding to 128 / 192 rows.  Those are the shapes for which lvq_attention_bf16 accepts the "mixed" operand
  * form q = hi + lo, k / v plain (k_lo = v_lo = NULL): Q-side rounding is common to all keys of a row and does not average out

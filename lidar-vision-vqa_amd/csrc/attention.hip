@@ -37,6 +37,10 @@ struct AttnArgs {
     int nsplit;       // KV splits (flash-decoding style) for few-queries x many-keys shapes
     int nqt;          // query tiles (of 64*QT queries)
     float *part;      // [B*H][nsplit][Nq][dh + 2] fp32 partial (unnormalised O | m | l) when nsplit > 1
+    // tiled key stream (k_attn32 only; bev_tiles.hip): tile t of batch b starts at row tile_src[b * ntiles + t] of k / v when that is
+    // >= 0 (live rows, shared by all batches: k_bs / v_bs are not applied) and at row ~tile_src of k_tab / v_tab otherwise
+    const int32_t *tile_src;
+    const uint16_t *k_tab, *v_tab;
 };
 
 constexpr int KVB = 64;  // keys per tile
@@ -591,8 +595,11 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
     // Three LDS slots: tile t+2 is requested at the top of tile t into the slot tile t-1 just left; tile t+1 has landed when a
     // counted vmcnt leaves exactly this wave's newest request in flight.
     const int wave_b = __builtin_amdgcn_readfirstlane(b), wave_hk = __builtin_amdgcn_readfirstlane(hk);
-    const uint16_t *kbase = a.k + (int64_t)wave_b * a.k_bs + (int64_t)wave_hk * a.k_hs;
-    const uint16_t *vbase = a.v + (int64_t)wave_b * a.v_bs + (int64_t)wave_hk * a.v_hs;
+    const bool tiled = a.tile_src != nullptr;                // kernel-uniform
+    const uint16_t *kbase = a.k + (tiled ? (int64_t)0 : (int64_t)wave_b * a.k_bs) + (int64_t)wave_hk * a.k_hs;
+    const uint16_t *vbase = a.v + (tiled ? (int64_t)0 : (int64_t)wave_b * a.v_bs) + (int64_t)wave_hk * a.v_hs;
+    const uint16_t *ktab = tiled ? a.k_tab + (int64_t)wave_hk * a.k_hs : nullptr;
+    const uint16_t *vtab = tiled ? a.v_tab + (int64_t)wave_hk * a.v_hs : nullptr;
     const int r8 = lane >> 3, pch = lane & 7;
     constexpr int NPC = (16 + NW - 1) / NW;                    // DMA pieces per wave per tile (K pieces 0..7, V pieces 8..15)
     // per piece: a loop-invariant 32-bit lane offset; the tile base is a scalar 64-bit add (a per-tile 64-bit multiply per
@@ -605,8 +612,27 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
         doff[j] = (uint32_t)(row * (isv ? a.ldv : a.ldk) + ((pch ^ f) << 3));
     }
     const int64_t kstep = (int64_t)KVB * a.ldk, vstep = (int64_t)KVB * a.ldv;
+    // tiled stream: lane l keeps the source row of tile tsv_base + l; a tile's row is a v_readlane away (no memory operation in
+    // the per-tile path: a scalar load there would sit in lgkmcnt beside the counted LDS waits), refreshed every 64 tiles
+    const int32_t *tsrc_b = tiled ? a.tile_src + (int64_t)wave_b * (a.Nkv / KVB) : nullptr;
+    int tsv_base = 0, tsv = 0;
+    auto tsv_load = [&](int tb) __attribute__((always_inline)) {
+        tsv_base = tb;
+        const int n_t = a.Nkv / KVB, tt = tb + lane;
+        tsv = tsrc_b[tt < n_t ? tt : n_t - 1];
+    };
     auto dma = [&](int t, int slot) __attribute__((always_inline)) {
-        const uint16_t *kt = kbase + t * kstep, *vt = vbase + t * vstep;       // wave-uniform
+        const uint16_t *kt, *vt;                                               // wave-uniform
+        if (tiled) {
+            if (t - tsv_base >= 64) tsv_load(t);
+            const int src = __builtin_amdgcn_readlane(tsv, t - tsv_base);
+            const int64_t row = src >= 0 ? src : ~src;
+            kt = (src >= 0 ? kbase : ktab) + row * a.ldk;
+            vt = (src >= 0 ? vbase : vtab) + row * a.ldv;
+        } else {
+            kt = kbase + t * kstep;
+            vt = vbase + t * vstep;
+        }
 #pragma unroll
         for (int j = 0; j < NPC; ++j) {
             const int pc = wid + NW * j;                       // wave-uniform
@@ -769,6 +795,7 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
     auto stream = [&](auto slow_tag) __attribute__((always_inline)) {
         constexpr bool SLOW = decltype(slow_tag)::value;
         slot = 0;
+        if (tiled) tsv_load(t0);
         if (t0 < t1) dma(t0, 0);
         if (t0 + 1 < t1) dma(t0 + 1, 1);
         if (t0 + 1 < t1) {                                     // tile t0 landed, tile t0+1 may still fly
@@ -1111,6 +1138,58 @@ extern "C" size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, 
 
 extern "C" int lvq_attention_stream_ok(int nq, int nkv, int dh) { return plan_k32_waves(nq, nkv, dh, false) != 0; }
 
+// VATLiDAR's cross-attention over the TILED key stream of bev_tiles.hip: batch b attends to n_tiles x 64 keys, tile t read from row
+// tile_src[b * n_tiles + t] of the live K|V rows (>= 0) or from row ~tile_src of the per-model table.  Long-stream kernel only
+// (head_dim 64, n_tiles * 64 >= 4096, lvq_attention_stream_ok(nq, 64 n_tiles, 64)); q plain or hi + lo, K / V plain.
+extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_live, const lvq_bf16 *v_live,
+                                        const lvq_bf16 *k_table, const lvq_bf16 *v_table, const int32_t *tile_src, int batch, int n_heads,
+                                        int nq, int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv,
+                                        int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o,
+                                        lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+    if (batch <= 0 || n_heads <= 0 || nq < 0 || n_tiles <= 0 || !q || !k_live || !v_live || !k_table || !v_table || !tile_src || !o) return LVQ_EINVAL;
+    if (nq == 0) return LVQ_OK;
+    const int64_t nkv64 = (int64_t)n_tiles * KVB;
+    if (nkv64 > 0x7fffffff) return LVQ_EUNSUPPORTED;
+    const int nkv = (int)nkv64;
+    if (dh != 64 || (ldq & 7) || (ldkv & 7) || (q_hstride & 7) || (kv_hstride & 7) || (q_bstride & 7) || (ldo & 3) || (o_hstride & 3) || (o_bstride & 3))
+        return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)q | (uintptr_t)q_lo | (uintptr_t)k_live | (uintptr_t)v_live | (uintptr_t)k_table | (uintptr_t)v_table) & 15) return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)o | (uintptr_t)o_lo) & 7) return LVQ_EUNSUPPORTED;
+    if (n_heads > 65535 || batch > 65535) return LVQ_EUNSUPPORTED;
+    AttnArgs a;
+    a.q = q; a.ql = q_lo; a.k = k_live; a.kl = nullptr; a.v = v_live; a.vl = nullptr; a.bias = nullptr;
+    a.B = batch; a.H = n_heads; a.Hkv = n_heads; a.Nq = nq; a.Nkv = nkv; a.dh = dh;
+    a.q_bs = q_bstride; a.ldq = ldq; a.q_hs = q_hstride; a.k_bs = 0; a.ldk = ldkv; a.k_hs = kv_hstride;
+    a.v_bs = 0; a.ldv = ldkv; a.v_hs = kv_hstride; a.o_bs = o_bstride; a.ldo = ldo; a.o_hs = o_hstride;
+    a.scale = scale; a.causal = 0; a.o = o; a.ol = o_lo;
+    a.tile_src = tile_src; a.k_tab = k_table; a.v_tab = v_table;
+    const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, false, true);
+    if (!pl.k32) return LVQ_EUNSUPPORTED;
+    a.nsplit = pl.nsplit; a.nqt = pl.nqt; a.part = nullptr;
+    if (pl.nsplit > 1) {
+        LvqArena arena(ws, ws_bytes);
+        a.part = arena.take<float>((size_t)batch * n_heads * pl.nsplit * nq * (dh + 2));
+        if (!arena.ok) return LVQ_EWORKSPACE;
+    }
+    hipStream_t st = lvq_s(stream);
+    const size_t lds = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16;
+    const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
+    const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;
+    if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
+    if (q_lo) {
+        if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 1>), dim3((unsigned)nwg), dim3(384), lds, st, a);
+        else              hipLaunchKernelGGL((k_attn32<4, 1>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    } else {
+        if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 0>), dim3((unsigned)nwg), dim3(384), lds, st, a);
+        else              hipLaunchKernelGGL((k_attn32<4, 0>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    }
+    if (a.nsplit > 1) {
+        const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
+        hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
+    }
+    return lvq_launch_status();
+}
+
 extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k, const lvq_bf16 *k_lo,
                                   const lvq_bf16 *v, const lvq_bf16 *v_lo, const float *bias, int batch, int n_heads,
                                   int n_kv_heads, int nq, int nkv, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride,
@@ -1143,6 +1222,7 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
         a.q_bs = q_bstride; a.ldq = ldq; a.q_hs = q_hstride; a.k_bs = k_bstride; a.ldk = ldk; a.k_hs = k_hstride;
         a.v_bs = v_bstride; a.ldv = ldv; a.v_hs = v_hstride; a.o_bs = o_bstride; a.ldo = ldo; a.o_hs = o_hstride;
         a.scale = scale; a.causal = causal; a.o = o; a.ol = o_lo;
+        a.tile_src = nullptr; a.k_tab = nullptr; a.v_tab = nullptr;
         const int dhp = (dh + 31) / 32 * 32;
         const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, split, bias == nullptr && !causal && (o_lo == nullptr || qsplit));
         if (qsplit && !pl.k32) return LVQ_EUNSUPPORTED;

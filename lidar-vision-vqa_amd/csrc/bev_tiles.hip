@@ -1,0 +1,450 @@
+// csrc/bev_tiles.hip -- the sparse BEV key stream of VATLiDAR (vat_lidar.py:212-248 + vat_blocks.py:42), gfx950.
+//
+// A BEV cell whose 3x3 neighbourhood holds no pillar yields a token that depends on the weights only:
+//     x[cell] = LayerNorm(proj(GELU(b_dw))) + PE[cell]        (refine conv -> 1x1 conv -> LayerNorm -> positional table)
+// and so do its K|V rows.  At nuScenes densities that is ~3/4 of the 512 x 512 cells.  The stream is therefore cut into
+// 8 x 8-cell TILES (64 keys = one attention K/V tile; key order is free under softmax, so keys run tile-major):
+//   * a tile whose 10 x 10 halo holds no pillar is CLEAN: its K|V rows come from a per-model table that is computed once per
+//     weights version by the very same kernels on an empty scene (bit-identical rows by construction);
+//   * every other tile is LIVE: its tokens are computed here, its K|V rows by the GEMM over the compacted live rows, and the
+//     attention kernel reads each tile through one row offset (lvq_attention_bf16_tiled).
+// This file holds (1) the tile bookkeeping: flags, compaction in (tile, scene) order so that the scenes sharing a positional
+// table tile run back to back, the per-(scene, tile) source offsets; and (2) the fused token kernel: pillar gather + depthwise
+// 3x3 + GELU (same tap order and fmaf chain as k_dwconv3x3_gelu) -> 1x1 conv on MFMA with W held in REGISTERS (column-
+// stationary: wave w owns N/8 output columns, so W is never re-read and needs no LDS) -> LayerNorm (per-wave (mean, M2)
+// partials merged with Chan's formula) -> + positional table -> bf16 rows, without any intermediate in HBM.
+#include "common.h"
+#include <type_traits>
+
+namespace bt {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    bf16x2_t p = {(__bf16)a, (__bf16)b};
+    return *reinterpret_cast<uint32_t *>(&p);
+}
+
+constexpr int TS = 8, TCELLS = 64, HALO = 10, NHALO = 100;
+
+// ---- tile flags: one thread per (scene, tile); live iff any pillar in the 10 x 10 halo (or `force`) ----
+__global__ void __launch_bounds__(256) k_tile_flags(const int32_t *__restrict__ idx, int S, int H, int W, int force, uint8_t *__restrict__ flags) {
+    const int tw = W / TS, th = H / TS, nt = tw * th;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (int64_t)S * nt) return;
+    const int s = (int)(g / nt), t = (int)(g % nt);
+    bool live = force != 0;
+    if (!live) {
+        const int y0 = (t / tw) * TS - 1, x0 = (t % tw) * TS - 1;
+        const int32_t *plane = idx + (int64_t)s * H * W;
+        for (int r = 0; r < HALO && !live; ++r) {
+            const int gy = y0 + r;
+            if (gy < 0 || gy >= H) continue;
+            for (int c = 0; c < HALO; ++c) {
+                const int gx = x0 + c;
+                if (gx >= 0 && gx < W && plane[(int64_t)gy * W + gx] >= 0) { live = true; break; }
+            }
+        }
+    }
+    flags[(int64_t)t * S + s] = live ? 1 : 0;            // (tile, scene) order
+}
+
+// ---- compaction: exclusive scan of the flags in (tile, scene) order (single workgroup; <= 4 M flags) ----
+//   live_list[k]           = t * S + s of the k-th live tile
+//   tile_src[s * nt + t]   = 64 * k (first row of the tile in the live buffer)  or  ~(64 * t) (row of the table) when clean
+//   counts[0] = number of live tiles, counts[1] = live rows (64 x)
+__global__ void __launch_bounds__(1024) k_tile_compact(const uint8_t *__restrict__ flags, int S, int nt, int32_t *__restrict__ live_list,
+                                                      int32_t *__restrict__ tile_src, int32_t *__restrict__ counts) {
+    __shared__ int wave_tot[16];
+    const int64_t total = (int64_t)S * nt;
+    const int per = (int)((total + 1023) / 1024);
+    const int64_t b0 = (int64_t)threadIdx.x * per;
+    int c = 0;
+    for (int j = 0; j < per; ++j)
+        if (b0 + j < total) c += flags[b0 + j];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) wave_tot[wid] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        const int t = wave_tot[w];
+        if (w < wid) base += t;
+        tot += t;
+    }
+    int k = base + incl - c;
+    for (int j = 0; j < per; ++j) {
+        const int64_t i = b0 + j;
+        if (i >= total) break;
+        const int t = (int)(i / S), s = (int)(i % S);
+        if (flags[i]) {
+            live_list[k] = (int32_t)i;
+            tile_src[(int64_t)s * nt + t] = k * TCELLS;
+            ++k;
+        } else {
+            tile_src[(int64_t)s * nt + t] = ~(t * TCELLS);
+        }
+    }
+    if (threadIdx.x == 0) { counts[0] = tot; counts[1] = tot * TCELLS; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fused token kernel.  512 threads = 8 waves; persistent over the live list.
+//   J   = 16-column MFMA tiles per wave (N = 128 J: 768 -> 6, 1024 -> 8, 512 -> 4, 256 -> 2; even, so a lane's 8 J output bytes stay 16-byte aligned)
+//   X3  = operands hi + lo (t and W), products hi*hi + hi*lo + lo*hi
+//   OLO = also write the lo half of x (bf16x3 consumers); the mixed mode keeps x plain
+// Product orientation: A = W rows (the wave's columns), B = t tile (16 cells x 64 k) -> C[row = column, col = cell]; with the
+// W row permutation n = 16 J w + 4 J (m >> 2) + 4 j + (m & 3) for A row m of column tile j, lane (cell = l & 15, g4 = l >> 4)
+// owns the 4 J CONSECUTIVE columns 16 J w + 4 J g4 .. of its cell: positional-table reads are J float4 and the output leaves
+// as J/2 (or so) 16-byte stores, 4 lanes covering 32 J contiguous bytes of a row.
+// Per tile: [B1: t tile ready] DMA of the next tile's pillar rows, pass 1 (MFMA -> per-wave (mean, M2)), [B2] conv of the next
+// tile (LDS only), pass 2 (MFMA again -> normalise -> + table -> store): two barriers, no HBM intermediate.
+// ---------------------------------------------------------------------------------------------------------
+struct TokArgs {
+    const float *feat;            // [M, 64] pillar features
+    const int32_t *idx;           // [S, H, W] pillar row or -1
+    const int32_t *live_list;     // (tile, scene) codes
+    const int32_t *counts;        // counts[0] = live tiles
+    const float *w9, *b9;         // depthwise conv [64, 9], [64]
+    const uint16_t *wh, *wl;      // 1x1 conv [N, 64] bf16 hi / lo
+    const float *bias, *gamma, *beta, *pe;     // [N], [N], [N], positional table [H*W (tile-major), N]
+    float eps;
+    int S, H, W;
+    uint16_t *xh, *xl;            // [cap * 64, N]
+};
+
+template <int J, bool X3, bool OLO>
+__global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
+    constexpr int N = 128 * J, C = 64, NWV = 8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // LDS map
+    uint16_t *t_hi = reinterpret_cast<uint16_t *>(smem);                      // [2][64][64] bf16, 128-byte rows, chunk-swizzled
+    uint16_t *t_lo = t_hi + 2 * TCELLS * C;                                   // [2][64][64]
+    float *halo = reinterpret_cast<float *>(t_lo + 2 * TCELLS * C);           // [100][64] fp32 pillar rows of the halo (live slots only)
+    int32_t *idxh = reinterpret_cast<int32_t *>(halo + NHALO * C);            // [2][128]
+    float *part = reinterpret_cast<float *>(idxh + 2 * 128);                  // [2][8 waves][64 cells][2]
+    float *pbias = part + 2 * NWV * TCELLS * 2, *pgam = pbias + N, *pbet = pgam + N;
+    float *w9s = pbet + N;                                                    // [9][64]
+    float *b9s = w9s + 9 * C;                                                 // [64]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const int tw = a.W / TS, nt = tw * (a.H / TS);
+    const int n_live = a.counts[0];
+
+    for (int e = tid; e < N; e += 512) { pbias[e] = a.bias ? a.bias[e] : 0.f; pgam[e] = a.gamma[e]; pbet[e] = a.beta ? a.beta[e] : 0.f; }
+    for (int e = tid; e < 9 * C; e += 512) w9s[e] = a.w9[(e % C) * 9 + e / C];
+    if (tid < C) b9s[tid] = a.b9 ? a.b9[tid] : 0.f;
+
+    // W fragments (A operand) in registers: lane (m = l15, kc = g4) holds W[n(m, j)][8 kc .. +7] and [32 + 8 kc .. +7]
+    bf16x8 wf[J][2], wfl[X3 ? J : 1][2];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int n = 16 * J * wid + 4 * J * (l15 >> 2) + 4 * j + (l15 & 3);
+        wf[j][0] = *reinterpret_cast<const bf16x8 *>(a.wh + (int64_t)n * C + 8 * g4);
+        wf[j][1] = *reinterpret_cast<const bf16x8 *>(a.wh + (int64_t)n * C + 32 + 8 * g4);
+        if (X3) {
+            wfl[j][0] = *reinterpret_cast<const bf16x8 *>(a.wl + (int64_t)n * C + 8 * g4);
+            wfl[j][1] = *reinterpret_cast<const bf16x8 *>(a.wl + (int64_t)n * C + 32 + 8 * g4);
+        }
+    }
+    const int col0 = 16 * J * wid + 4 * J * g4;                  // this lane's first column (4 J consecutive ones)
+
+    // work order: 8 consecutive list entries (same positional tile, different scenes) go to workgroups of one XCD (ids 8 apart)
+    auto entry_of = [&](int64_t v) -> int64_t {
+        const int64_t grp = v >> 6;
+        const int within = (int)(v & 63);
+        return grp * 64 + (within & 7) * 8 + (within >> 3);
+    };
+    const int64_t n_pad = ((int64_t)n_live + 63) / 64 * 64;
+    auto tile_at = [&](int64_t it, int &s, int &t, int64_t &k) -> bool {      // it-th tile of this workgroup
+        const int64_t v = (int64_t)blockIdx.x + it * gridDim.x;
+        if (v >= n_pad) return false;
+        k = entry_of(v);
+        if (k >= n_live) { s = -1; t = 0; return true; }                       // padding slot of the permutation: nothing to do
+        const int code = a.live_list[k];
+        t = code / a.S; s = code - t * a.S;
+        return true;
+    };
+    // halo indices of a tile -> idxh[buf] (threads 0..99)
+    auto load_idx = [&](int s, int t) -> int {
+        if (tid >= NHALO || s < 0) return -1;
+        const int gy = (t / tw) * TS - 1 + tid / HALO, gx = (t % tw) * TS - 1 + tid % HALO;
+        return (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? a.idx[((int64_t)s * a.H + gy) * a.W + gx] : -1;
+    };
+    // LDS-DMA of the live halo rows (256 B each): 4 slots per wave instruction, 16 lanes per slot; empty slots are skipped
+    auto dma_halo = [&](const int32_t *ih) {
+        for (int p = wid; p < NHALO / 4; p += NWV) {
+            const int slot = p * 4 + (lane >> 4);
+            const int row = ih[slot];
+            if (row >= 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.feat + (int64_t)row * C + 4 * l15),
+                                                 (__attribute__((address_space(3))) void *)(halo + p * 4 * C), 16, 0, 0);
+        }
+    };
+    // depthwise 3x3 + GELU of one tile from the staged halo rows: thread (cell = tid >> 3, channels 8 (tid & 7) .. +7)
+    auto conv_tile = [&](const int32_t *ih, int buf) {
+        const int cell = tid >> 3, cg = (tid & 7) * 8, cy = cell >> 3, cx = cell & 7;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = b9s[cg + c];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int slot = (cy + rr) * HALO + cx + k;
+                if (ih[slot] >= 0) {                              // a zero tap leaves the accumulator unchanged exactly
+                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(halo + slot * C + cg), v1 = *reinterpret_cast<const f32x4 *>(halo + slot * C + cg + 4);
+                    const f32x4 k0 = *reinterpret_cast<const f32x4 *>(w9s + (rr * 3 + k) * C + cg), k1 = *reinterpret_cast<const f32x4 *>(w9s + (rr * 3 + k) * C + cg + 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { acc[c] = fmaf(v0[c], k0[c], acc[c]); acc[4 + c] = fmaf(v1[c], k1[c], acc[4 + c]); }
+                }
+            }
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float y0 = gelu_erf(acc[2 * c]), y1 = gelu_erf(acc[2 * c + 1]);
+            hi[c] = pack_bf16(y0, y1);
+            lo[c] = pack_bf16(y0 - __uint_as_float(hi[c] << 16), y1 - __uint_as_float(hi[c] & 0xffff0000u));
+        }
+        const int ch = (tid & 7) ^ ((cell >> 1) & 7);             // 16-byte chunk swizzle (as the GEMM tiles: conflict-free fragment reads)
+        *reinterpret_cast<u32x4 *>(t_hi + (buf * TCELLS + cell) * C + ch * 8) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        if (X3) *reinterpret_cast<u32x4 *>(t_lo + (buf * TCELLS + cell) * C + ch * 8) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    };
+    // the product of one 16-cell group for HALF of this wave's columns (column tiles j = HF * J/2 .. +J/2): acc[j] = bias + W t
+    // (two K halves; x3: + cross terms).  Halves keep the live accumulators at 2 J registers (J = 6 x3 spilled otherwise).
+    constexpr int JH = J / 2;
+    auto load_t = [&](int buf, int gq, bf16x8 &th0, bf16x8 &th1, bf16x8 &tl0, bf16x8 &tl1) {
+        const int row = gq * 16 + l15;
+        const int c0 = (g4 ^ ((row >> 1) & 7)) * 8, c1 = ((4 + g4) ^ ((row >> 1) & 7)) * 8;
+        th0 = *reinterpret_cast<const bf16x8 *>(t_hi + (buf * TCELLS + row) * C + c0);
+        th1 = *reinterpret_cast<const bf16x8 *>(t_hi + (buf * TCELLS + row) * C + c1);
+        if (X3) {
+            tl0 = *reinterpret_cast<const bf16x8 *>(t_lo + (buf * TCELLS + row) * C + c0);
+            tl1 = *reinterpret_cast<const bf16x8 *>(t_lo + (buf * TCELLS + row) * C + c1);
+        }
+    };
+    // bias / gamma / beta are loop-invariant LDS reads: left alone, LICM hoists all 12 J of them into registers (248 VGPRs in the
+    // plain build, spills in the x3 one).  An opaque copy of the base pointer per use keeps them as LDS reads.
+    auto opaque = [](const float *p) { asm volatile("" : "+v"(p)); return p; };
+    auto product = [&](auto hf_tag, const bf16x8 &th0, const bf16x8 &th1, const bf16x8 &tl0, const bf16x8 &tl1, f32x4 (&acc)[JH]) {
+        constexpr int HF = decltype(hf_tag)::value;
+        const float *pb = opaque(pbias + col0);
+#pragma unroll
+        for (int jj = 0; jj < JH; ++jj) {
+            const int j = HF * JH + jj;
+            acc[jj] = *reinterpret_cast<const f32x4 *>(pb + 4 * j);
+            acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], th0, acc[jj], 0, 0, 0);
+            acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], th1, acc[jj], 0, 0, 0);
+            if (X3) {
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], tl0, acc[jj], 0, 0, 0);
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], tl1, acc[jj], 0, 0, 0);
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfl[j][0], th0, acc[jj], 0, 0, 0);
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfl[j][1], th1, acc[jj], 0, 0, 0);
+            }
+        }
+    };
+    // (mean, M2) of one lane group's 8 J values of a half, reduced over the four g4 lanes of the cell
+    auto half_stats = [&](const f32x4 (&acc)[JH], float &mean, float &m2) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < JH; ++jj) s1 += (acc[jj][0] + acc[jj][1]) + (acc[jj][2] + acc[jj][3]);
+        s1 += __shfl_xor(s1, 16);
+        s1 += __shfl_xor(s1, 32);
+        mean = s1 * (1.0f / (float)(16 * JH));
+        float q = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < JH; ++jj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float dlt = acc[jj][r] - mean; q = fmaf(dlt, dlt, q); }
+        q += __shfl_xor(q, 16);
+        q += __shfl_xor(q, 32);
+        m2 = q;
+    };
+
+    // ---- prologue: tile 0 staged synchronously, indices of tile 1 in LDS ----
+    int s_cur, t_cur, s_nx, t_nx, s_n2, t_n2;
+    int64_t k_cur, k_nx, k_n2;
+    bool has_cur = tile_at(0, s_cur, t_cur, k_cur);
+    bool has_nx = tile_at(1, s_nx, t_nx, k_nx);
+    if (tid < 128) { idxh[tid] = -1; idxh[128 + tid] = -1; }
+    __syncthreads();
+    if (!has_cur) return;
+    {
+        const int i0 = load_idx(s_cur, t_cur), i1 = has_nx ? load_idx(s_nx, t_nx) : -1;
+        if (tid < NHALO) { idxh[tid] = i0; idxh[128 + tid] = i1; }
+    }
+    __syncthreads();
+    dma_halo(idxh);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_tile(idxh, 0);
+    int buf = 0;
+    for (int64_t it = 0; has_cur; ++it) {
+        __syncthreads();                                          // B1: t[buf] complete, halo buffer free, part[buf] free
+        const int32_t *ih_nx = idxh + ((it + 1) & 1) * 128;
+        if (has_nx) dma_halo(ih_nx);
+        const bool has_n2 = tile_at(it + 2, s_n2, t_n2, k_n2);
+        const int i2 = has_n2 ? load_idx(s_n2, t_n2) : -1;
+        // ---- pass 1: per-wave (mean, M2) of every cell over this wave's 16 J columns ----
+        float *pw = part + ((buf * NWV + wid) * TCELLS) * 2;
+#pragma unroll 1
+        for (int gq = 0; gq < 4; ++gq) {
+            bf16x8 th0, th1, tl0, tl1;
+            load_t(buf, gq, th0, th1, tl0, tl1);
+            float ma, qa, mb, qb;
+            {
+                f32x4 acc[JH];
+                product(std::integral_constant<int, 0>{}, th0, th1, tl0, tl1, acc);
+                half_stats(acc, ma, qa);
+            }
+            {
+                f32x4 acc[JH];
+                product(std::integral_constant<int, 1>{}, th0, th1, tl0, tl1, acc);
+                half_stats(acc, mb, qb);
+            }
+            // two equal-sized halves (Chan): mean = (ma + mb) / 2, M2 = qa + qb + (mb - ma)^2 * n / 2 with n = 8 J per half
+            const float dlt = mb - ma;
+            const float mw = ma + 0.5f * dlt, m2 = qa + qb + dlt * dlt * (0.5f * (float)(16 * JH));
+            if (g4 == 0) { pw[(gq * 16 + l15) * 2] = mw; pw[(gq * 16 + l15) * 2 + 1] = m2; }
+        }
+        if (tid < NHALO) idxh[(it & 1) * 128 + tid] = i2;         // indices of tile it+2 replace those of tile it (its conv is done)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's halo DMA (tile it+1) has landed
+        __syncthreads();                                          // B2: partials complete; every wave's DMA landed
+        if (has_nx) conv_tile(ih_nx, buf ^ 1);
+        // ---- pass 2: merge the 8 partials (Chan), recompute, normalise, + table, store ----
+        if (s_cur >= 0) {
+            const float *pr = part + (buf * NWV * TCELLS) * 2;
+            const int64_t prow0 = (int64_t)t_cur * TCELLS, orow0 = k_cur * TCELLS;
+#pragma unroll 1
+            for (int gq = 0; gq < 4; ++gq) {
+                const int cell = gq * 16 + l15;
+                const float *pep = a.pe + (prow0 + cell) * N + col0;
+                f32x4 pe0[JH], pe1[JH];                            // requested up front (HBM), consumed per half
+#pragma unroll
+                for (int jj = 0; jj < JH; ++jj) pe0[jj] = *reinterpret_cast<const f32x4 *>(pep + 4 * jj);
+#pragma unroll
+                for (int jj = 0; jj < JH; ++jj) pe1[jj] = *reinterpret_cast<const f32x4 *>(pep + 4 * (JH + jj));
+                float mean = pr[cell * 2], m2 = pr[cell * 2 + 1], cnt = (float)(16 * J);
+#pragma unroll
+                for (int w = 1; w < NWV; ++w) {
+                    const float mb = pr[(w * TCELLS + cell) * 2], m2b = pr[(w * TCELLS + cell) * 2 + 1], nb = (float)(16 * J);
+                    const float dlt = mb - mean, tot = cnt + nb;
+                    mean += dlt * (nb / tot);
+                    m2 += m2b + dlt * dlt * (cnt * nb / tot);
+                    cnt = tot;
+                }
+                const float rstd = 1.0f / sqrtf(m2 / (float)N + a.eps);
+                bf16x8 th0, th1, tl0, tl1;
+                load_t(buf, gq, th0, th1, tl0, tl1);
+                uint16_t *dst = a.xh + (orow0 + cell) * N + col0;
+                uint16_t *dl = OLO ? a.xl + (orow0 + cell) * N + col0 : nullptr;
+                auto half_out = [&](auto hf_tag, const f32x4 (&pe)[JH]) {
+                    constexpr int HF = decltype(hf_tag)::value;
+                    f32x4 acc[JH];
+                    product(hf_tag, th0, th1, tl0, tl1, acc);
+                    uint32_t oh[2 * JH], ol[OLO ? 2 * JH : 1];
+                    const float *pg = opaque(pgam + col0), *pbt = opaque(pbet + col0);
+#pragma unroll
+                    for (int jj = 0; jj < JH; ++jj) {
+                        const int j = HF * JH + jj;
+                        const f32x4 gv = *reinterpret_cast<const f32x4 *>(pg + 4 * j), bv = *reinterpret_cast<const f32x4 *>(pbt + 4 * j);
+                        float y[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[r] = ((acc[jj][r] - mean) * rstd) * gv[r] + bv[r] + pe[jj][r];
+                        oh[2 * jj] = pack_bf16(y[0], y[1]);
+                        oh[2 * jj + 1] = pack_bf16(y[2], y[3]);
+                        if (OLO) {
+                            ol[2 * jj] = pack_bf16(y[0] - __uint_as_float(oh[2 * jj] << 16), y[1] - __uint_as_float(oh[2 * jj] & 0xffff0000u));
+                            ol[2 * jj + 1] = pack_bf16(y[2] - __uint_as_float(oh[2 * jj + 1] << 16), y[3] - __uint_as_float(oh[2 * jj + 1] & 0xffff0000u));
+                        }
+                    }
+                    // 4 J bytes per half and lane: J/2 8-byte pieces (16-byte stores where a pair is whole)
+                    static_assert(J % 2 == 0, "even J");
+#pragma unroll
+                    for (int q = 0; q < 2 * JH; q += 2) {
+                        *reinterpret_cast<uint2 *>(dst + 2 * (2 * HF * JH + q)) = make_uint2(oh[q], oh[q + 1]);
+                        if (OLO) *reinterpret_cast<uint2 *>(dl + 2 * (2 * HF * JH + q)) = make_uint2(ol[q], ol[q + 1]);
+                    }
+                };
+                half_out(std::integral_constant<int, 0>{}, pe0);
+                half_out(std::integral_constant<int, 1>{}, pe1);
+            }
+        }
+        // rotate
+        has_cur = has_nx; s_cur = s_nx; t_cur = t_nx; k_cur = k_nx;
+        has_nx = has_n2; s_nx = s_n2; t_nx = t_n2; k_nx = k_n2;
+        buf ^= 1;
+    }
+}
+
+}  // namespace bt
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" size_t lvq_bev_tiles_workspace_bytes(int batch, int ny, int nx) {
+    if (batch <= 0 || ny <= 0 || nx <= 0) return 0;
+    return lvq_align((size_t)batch * (ny / 8) * (nx / 8)) + 512;          // one flag byte per (tile, scene)
+}
+
+extern "C" int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, int force_all, int32_t *live_list, int32_t *tile_src,
+                             int32_t *counts, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+    if (batch <= 0 || ny <= 0 || nx <= 0 || !live_list || !tile_src || !counts || (!idx_map && !force_all)) return LVQ_EINVAL;
+    if ((ny % 8) || (nx % 8)) return LVQ_EUNSUPPORTED;
+    const int64_t nt = (int64_t)(ny / 8) * (nx / 8), total = nt * batch;
+    if (total > (1 << 22)) return LVQ_EUNSUPPORTED;
+    if (!ws || ws_bytes < lvq_bev_tiles_workspace_bytes(batch, ny, nx)) return LVQ_EWORKSPACE;
+    uint8_t *flags = (uint8_t *)ws;
+    hipStream_t st = lvq_s(stream);
+    hipLaunchKernelGGL(bt::k_tile_flags, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, flags);
+    hipLaunchKernelGGL(bt::k_tile_compact, dim3(1), dim3(1024), 0, st, flags, batch, (int)nt, live_list, tile_src, counts);
+    return lvq_launch_status();
+}
+
+template <int J> static int launch_tile_tokens(const bt::TokArgs &a, bool x3, bool olo, int64_t cap_tiles, hipStream_t st) {
+    const size_t lds = (size_t)2 * 2 * bt::TCELLS * 64 * 2 + (size_t)bt::NHALO * 64 * 4 + 2 * 128 * 4 + (size_t)2 * 8 * bt::TCELLS * 2 * 4 +
+                       (size_t)3 * 128 * J * 4 + 9 * 64 * 4 + 64 * 4;
+    static LvqLdsOnce once;
+    if (!lvq_ensure_lds(once, {(const void *)bt::k_tile_tokens<J, false, false>, (const void *)bt::k_tile_tokens<J, true, false>,
+                               (const void *)bt::k_tile_tokens<J, true, true>}, lds))
+        return LVQ_ELAUNCH;
+    int64_t grid = (int64_t)lvq_cu_count();
+    if (grid > cap_tiles) grid = cap_tiles;
+    grid = (grid + 7) / 8 * 8;                                     // whole groups of 8 (the XCD-aware entry order)
+    if (x3 && olo) hipLaunchKernelGGL((bt::k_tile_tokens<J, true, true>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    else if (x3)   hipLaunchKernelGGL((bt::k_tile_tokens<J, true, false>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    else           hipLaunchKernelGGL((bt::k_tile_tokens<J, false, false>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    return lvq_launch_status();
+}
+
+extern "C" int lvq_bev_tile_tokens(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *counts,
+                                   int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9, const lvq_bf16 *w,
+                                   const lvq_bf16 *w_lo, const float *bias, const float *gamma, const float *beta, float eps, const float *pe_tiled,
+                                   int n, lvq_bf16 *x, lvq_bf16 *x_lo, lvq_stream_t stream) {
+    if (batch <= 0 || ny <= 0 || nx <= 0 || cap_tiles <= 0 || !idx_map || !live_list || !counts || !w9 || !w || !gamma || !pe_tiled || !x)
+        return LVQ_EINVAL;
+    if (x_lo && !w_lo) return LVQ_EINVAL;
+    if (c_in != 64 || (ny % 8) || (nx % 8) || (n % 256) || n < 256 || n > 1024) return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)pillar_feat | (uintptr_t)w | (uintptr_t)w_lo | (uintptr_t)pe_tiled | (uintptr_t)x | (uintptr_t)x_lo | (uintptr_t)bias |
+         (uintptr_t)gamma | (uintptr_t)beta) & 15)
+        return LVQ_EUNSUPPORTED;
+    bt::TokArgs a;
+    a.feat = pillar_feat; a.idx = idx_map; a.live_list = live_list; a.counts = counts; a.w9 = w9; a.b9 = b9; a.wh = w; a.wl = w_lo;
+    a.bias = bias; a.gamma = gamma; a.beta = beta; a.pe = pe_tiled; a.eps = eps; a.S = batch; a.H = ny; a.W = nx; a.xh = x; a.xl = x_lo;
+    hipStream_t st = lvq_s(stream);
+    const bool x3 = w_lo != nullptr, olo = x_lo != nullptr;
+    switch (n / 128) {
+        case 2: return launch_tile_tokens<2>(a, x3, olo, cap_tiles, st);
+        case 4: return launch_tile_tokens<4>(a, x3, olo, cap_tiles, st);
+        case 6: return launch_tile_tokens<6>(a, x3, olo, cap_tiles, st);
+        case 8: return launch_tile_tokens<8>(a, x3, olo, cap_tiles, st);
+        default: return LVQ_EUNSUPPORTED;
+    }
+}

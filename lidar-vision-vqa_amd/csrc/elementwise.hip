@@ -635,6 +635,18 @@ extern "C" int lvq_dwconv3x3_gelu(const float *bev, const float *w9, const float
     return lvq_launch_status();
 }
 
+// PointPillarScatter as an INDEX map (pointpillar_scatter.py:14-37 without the canvas): idx[b, y, x] = pillar row or -1.
+extern "C" int lvq_pillar_index_map(const int32_t *coords_bzyx, int64_t m_cap, const int32_t *n_voxels_dev, int batch, int ny, int nx,
+                                    int32_t *idx_map, lvq_stream_t stream) {
+    if (m_cap < 0 || batch <= 0 || ny <= 0 || nx <= 0 || !idx_map || (m_cap > 0 && !coords_bzyx)) return LVQ_EINVAL;
+    if ((int64_t)batch * ny * nx >= (1ll << 31)) return LVQ_EOVERFLOW;
+    hipStream_t st = lvq_s(stream);
+    hipMemsetAsync(idx_map, 0xff, sizeof(int32_t) * (size_t)batch * ny * nx, st);
+    if (m_cap > 0)
+        hipLaunchKernelGGL(k_pillar_index, dim3((unsigned)lvq_cdiv(m_cap, 256)), dim3(256), 0, st, coords_bzyx, m_cap, n_voxels_dev, batch, ny, nx, idx_map);
+    return lvq_launch_status();
+}
+
 extern "C" size_t lvq_pillar_dwconv_workspace_bytes(int batch, int ny, int nx) {
     return lvq_align((size_t)batch * ny * nx * sizeof(int32_t)) + 256;
 }

@@ -49,6 +49,7 @@ struct GemmArgs {
     float *c32;
     uint16_t *c16, *c16lo;
     int ntx;            // tiles along N
+    const int32_t *m_dev;   // k_gemm_256 only: the live row count lives on the device (sparse BEV stream); rows [*m_dev, M) are skipped
     int vec_epilogue;   // every C-side pointer / stride is 8-element aligned -> LDS-transposed 16-byte stores
     int stream_c;       // C (and the residual) is large and not re-read by this launch: non-temporal loads / stores
 };
@@ -495,7 +496,16 @@ __global__ void __launch_bounds__(512) k_gemm_256(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 2, wn = wid & 3;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // device-side row count: the grid covers the capacity, the workgroups past the live rows leave at once, and the XCD-aware
+    // order is taken over the LIVE tile count (over the grid it would park all the work on the first XCDs)
+    int n_act = gridDim.x;
+    if (g.m_dev) {
+        int64_t live = *g.m_dev;
+        live = live < 0 ? 0 : (live > g.M ? g.M : live);
+        n_act = (int)((live + BM - 1) / BM) * g.ntx;
+        if ((int)blockIdx.x >= n_act) return;
+    }
+    const int tile = xcd_remap(blockIdx.x, n_act);
     const int64_t m0 = (int64_t)(tile / g.ntx) * BM;
     const int n0 = (tile % g.ntx) * BN;
     const int64_t z = blockIdx.z;
@@ -1213,6 +1223,7 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
         return lvq_launch_status();
     }
     GemmArgs g;
+    g.m_dev = nullptr;
     g.nseg = a_lo ? 3 : (w_lo ? 2 : 1);
     g.a[0] = a; g.w[0] = w;
     g.a[1] = a; g.w[1] = w_lo;
@@ -1283,6 +1294,33 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
         else     { if (ge) LVQ_LAUNCH(64, 0, 1); else LVQ_LAUNCH(64, 0, 0); }
     }
 #undef LVQ_LAUNCH
+    return lvq_launch_status();
+}
+
+// The K|V projection over the LIVE rows of the sparse BEV stream (bev_tiles.hip): c[0 .. *m_rows_dev) = a @ w^T + bias on the 256 x 256
+// tile kernel, rows past the device-side count untouched.  m_cap (the buffers' row capacity) and n multiples of 256, k of 64.
+extern "C" int lvq_gemm_bf16_live_rows(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,
+                                       int64_t m_cap, const int32_t *m_rows_dev, int n, int k, int64_t lda, int64_t ldw, int64_t ldc,
+                                       lvq_bf16 *c_bf16, lvq_bf16 *c_lo, lvq_stream_t stream) {
+    if (m_cap <= 0 || n <= 0 || k <= 0 || !a || !w || !c_bf16 || !m_rows_dev) return LVQ_EINVAL;
+    if (a_lo != nullptr && w_lo == nullptr) return LVQ_EINVAL;
+    if ((m_cap % 256) || (n % 256) || (k % 64) || (lda & 7) || (ldw & 7) || (ldc & 7) || lda < k || ldw < k || ldc < n) return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)a_lo | (uintptr_t)w_lo | (uintptr_t)c_bf16 | (uintptr_t)c_lo | (uintptr_t)bias) & 15) return LVQ_EUNSUPPORTED;
+    if ((m_cap / 256) * (n / 256) > 0x7fffffff) return LVQ_EUNSUPPORTED;
+    GemmArgs g;
+    g.m_dev = m_rows_dev;
+    g.nseg = a_lo ? 3 : (w_lo ? 2 : 1);
+    g.a[0] = a; g.w[0] = w; g.a[1] = a; g.w[1] = w_lo; g.a[2] = a_lo; g.w[2] = w;
+    g.bias = bias; g.residual = nullptr; g.rowtab = nullptr; g.rowtab_rows = 0; g.alpha = 1.0f; g.flags = 0;
+    g.M = m_cap; g.N = n; g.K = k; g.lda = lda; g.ldw = ldw; g.ldc = ldc; g.a_bs = 0; g.w_bs = 0; g.c_bs = 0;
+    g.c32 = nullptr; g.c16 = c_bf16; g.c16lo = c_lo; g.stream_c = 1; g.vec_epilogue = 1;
+    g.ntx = n / 256;
+    const size_t lds = (size_t)5 * 256 * 128;
+    static LvqLdsOnce once;
+    if (!lvq_ensure_lds(once, {(const void *)k_gemm_256<0, 0>, (const void *)k_gemm_256<0, 1>}, lds)) return LVQ_ELAUNCH;
+    dim3 grid((unsigned)((m_cap / 256) * (n / 256)), 1, 1);
+    if (g.ntx <= 8) hipLaunchKernelGGL((k_gemm_256<0, 1>), grid, dim3(512), lds, lvq_s(stream), g);
+    else            hipLaunchKernelGGL((k_gemm_256<0, 0>), grid, dim3(512), lds, lvq_s(stream), g);
     return lvq_launch_status();
 }
 

@@ -21,6 +21,7 @@ as in the reference's eval() mode.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -134,6 +135,26 @@ class VATBlock(_HipModule):
                           scale=1.0 / math.sqrt(dh), tag="ca_attn")
         y, _ = ops.linear(o, self._w(self.ca.out_proj.weight), self.ca.out_proj.bias, residual=q2, out_f32=True, tag="ca_out_proj")
         return y
+
+    def _cross_attn_tiled(self, q2: torch.Tensor, x_live: BF, kv_table: torch.Tensor, tile_src: torch.Tensor, rows_dev: torch.Tensor,
+                          B: int, nq: int, n_tiles: int) -> torch.Tensor:
+        """Cross-attention over the tiled BEV key stream (csrc/bev_tiles.hip): K|V of the LIVE rows from x_live here, clean tiles
+        from the per-model table.  Plain K / V / P; weights and the query side keep their lo parts in the mixed mode."""
+        d, h = self.d_model, self.n_heads
+        dh = d // h
+        split = self._split()
+        kv_live, _ = ops.linear_live_rows(x_live, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, rows_dev, (d, 3 * d), tag="ca_kv_proj")
+        _, qn = ops.layernorm(q2, self.ca_ln.weight, self.ca_ln.bias, self.ca_ln.eps, split)
+        _, qp = ops.linear(qn, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(0, d), tag="ca_q_proj")
+        o = ops.attention_tiled(qp, kv_live, kv_table, tile_src, batch=B, n_heads=h, nq=nq, n_tiles=n_tiles, dh=dh,
+                                scale=1.0 / math.sqrt(dh), tag="ca_attn")
+        y, _ = ops.linear(o, self._w(self.ca.out_proj.weight), self.ca.out_proj.bias, residual=q2, out_f32=True, tag="ca_out_proj")
+        return y
+
+    def forward_tokens_tiled(self, q2, x_live, kv_table, tile_src, rows_dev, B, nq, n_tiles) -> torch.Tensor:
+        q2 = self._self_attn(q2, B, nq)
+        q2 = self._cross_attn_tiled(q2, x_live, kv_table, tile_src, rows_dev, B, nq, n_tiles)
+        return self._mlp(q2)
 
     def _mlp(self, q2: torch.Tensor) -> torch.Tensor:
         split = self._split()
@@ -271,16 +292,84 @@ class VATLiDAR(_HipModule):
         _, x = ops.layernorm(x32, self.norm_tokens.weight, self.norm_tokens.bias, self.norm_tokens.eps, self._split() and not plain_x, post=pe)
         return x
 
+    # ---- sparse (tiled) key stream: csrc/bev_tiles.hip ------------------------------------------------------------------
+    def _tiled_route_ok(self, C: int, H: int, W: int) -> bool:
+        """Pillar route with 8 x 8-cell key tiles: 64-channel pillars, grid sides multiples of 8, a width the fused token kernel
+        builds, head_dim 64 and a key stream long enough for the long-stream attention kernel; plain or mixed operands (bf16x3
+        keeps lo parts of K / V, which the tiled kernels do not carry)."""
+        blk = self.blocks[0]
+        return (C == 64 and H % 8 == 0 and W % 8 == 0 and self.d_model in (256, 512, 768, 1024) and blk.d_model // blk.n_heads == 64
+                and self._mode() in ("bf16", "mixed") and ops.attention_stream_ok(self.n_queries, H * W, 64)
+                and not os.environ.get("LVQ_NO_TILED_STREAM"))
+
+    def _pe_tiled(self, H: int, W: int, dev) -> torch.Tensor:
+        """The positional table with its rows in tile-major order (row 64 t + 8 y + x of tile t): a permutation of _pe_table."""
+        pe = self._pe_table(H, W, dev)
+        hit = self._pe_cache.get(("tiled", H, W, dev))
+        if hit is not None and hit[0] is pe:
+            return hit[1]
+        d = pe.shape[1]
+        pt = pe.view(H // 8, 8, W // 8, 8, d).permute(0, 2, 1, 3, 4).reshape(H * W, d).contiguous()
+        self._pe_cache[("tiled", H, W, dev)] = (pe, pt)
+        return pt
+
+    def _tile_tokens(self, feat, idx, live, counts, cap_rows, batch, H, W) -> BF:
+        C = feat.shape[1]
+        return ops.bev_tile_tokens(feat, idx, live, counts, cap_rows, batch, H, W, self.refine[0].weight.detach().reshape(C, 9).contiguous(),
+                                   self.refine[0].bias, self._w(self.proj.weight), self.proj.bias, self.norm_tokens.weight, self.norm_tokens.bias,
+                                   self.norm_tokens.eps, self._pe_tiled(H, W, feat.device), out_lo=False, tag="bev_proj_ln")
+
+    def _kv_tables(self, C: int, H: int, W: int, dev) -> List[torch.Tensor]:
+        """Per layer: K|V rows [H*W, 2d] of the EMPTY scene, by the same kernels that serve the live tiles (every tile forced
+        live), cached per weights version and precision mode -- input-independent like the positional table."""
+        params = [self.refine[0].weight, self.refine[0].bias, self.proj.weight, self.proj.bias, self.norm_tokens.weight, self.norm_tokens.bias,
+                  self.geo_mlp[0].weight, self.geo_mlp[0].bias, self.geo_mlp[2].weight, self.geo_mlp[2].bias, self.view_embed]
+        for blk in self.blocks:
+            params += [blk.ca.in_proj_weight, blk.ca.in_proj_bias]
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(),)
+        key = ("kv_table", H, W, dev)
+        hit = self._pe_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        nt = (H // 8) * (W // 8)
+        idx = torch.full((1, H, W), -1, dtype=torch.int32, device=dev)
+        live, src, counts = ops.bev_tiles(idx, 1, H, W, dev, force_all=True)
+        feat = torch.zeros((1, C), dtype=torch.float32, device=dev)
+        x = self._tile_tokens(feat, idx, live, counts, nt * 64, 1, H, W)
+        d = self.d_model
+        tables = []
+        for blk in self.blocks:
+            blk.precision = self.precision
+            kv, _ = ops.linear_live_rows(x, blk._w(blk.ca.in_proj_weight), blk.ca.in_proj_bias, counts[1:], (d, 3 * d))
+            tables.append(kv)
+        self._pe_cache[key] = (ver, tables)
+        return tables
+
     def forward_pillars(self, pillar_features: torch.Tensor, coords_bzyx: torch.Tensor, n_live: Optional[torch.Tensor],
-                        batch: int, H: int, W: int) -> torch.Tensor:
-        """Same result as forward(PointPillarScatter(pillars)) without the dense BEV canvas: the scatter and the refine conv
-        (vat_lidar.py:212-221) run as one sparse gather (ops.pillar_dwconv3x3_gelu, bit-identical tokens)."""
+                        batch: int, H: int, W: int, all_tiles_live: bool = False) -> torch.Tensor:
+        """Same result as forward(PointPillarScatter(pillars)) without the dense BEV canvas.  Default route (shapes of
+        _tiled_route_ok): the sparse key stream of csrc/bev_tiles.hip -- tokens and K|V only for the tiles that hold a pillar in
+        their halo, the rest from the per-model table; `all_tiles_live=True` computes every tile per scene (the dense comparator:
+        the two are bit-identical).  Other shapes: scatter + refine conv as one sparse gather (ops.pillar_dwconv3x3_gelu)."""
         self._guard(pillar_features)
         C = pillar_features.shape[1]
-        t = ops.pillar_dwconv3x3_gelu(_f32(pillar_features), coords_bzyx, n_live, batch, H, W,
-                                      self.refine[0].weight.detach().reshape(C, 9).contiguous(), self.refine[0].bias, self._split())
-        x = self._tokens_to_model(t, H, W, pillar_features.device)
-        return self._decode(x, batch, H, W)
+        dev = pillar_features.device
+        feat = _f32(pillar_features)
+        if not self._tiled_route_ok(C, H, W) or (H // 8) * (W // 8) * 64 % 256:
+            t = ops.pillar_dwconv3x3_gelu(feat, coords_bzyx, n_live, batch, H, W,
+                                          self.refine[0].weight.detach().reshape(C, 9).contiguous(), self.refine[0].bias, self._split())
+            return self._decode(self._tokens_to_model(t, H, W, dev), batch, H, W)
+        nt = (H // 8) * (W // 8)
+        tables = self._kv_tables(C, H, W, dev)
+        idx = ops.pillar_index_map(coords_bzyx, n_live, batch, H, W)
+        live, src, counts = ops.bev_tiles(idx, batch, H, W, dev, force_all=all_tiles_live)
+        x_live = self._tile_tokens(feat, idx, live, counts, batch * nt * 64, batch, H, W)
+        q2 = self._queries(batch)
+        for blk, table in zip(self.blocks, tables):
+            blk.precision = self.precision
+            q2 = blk.forward_tokens_tiled(q2, x_live, table, src, counts[1:], batch, self.n_queries, nt)
+        self._last_tile_counts = counts                       # device tensor (live tiles, live rows): read by bench / tests only
+        return _post_head(self, q2, self.final_ln, self.post).view(batch, self.n_queries, self.d_model)
 
     def forward(self, bev: torch.Tensor) -> torch.Tensor:
         self._guard(bev)
@@ -288,11 +377,14 @@ class VATLiDAR(_HipModule):
         x = self.bev_tokens(bev)
         return self._decode(x, B, H, W)
 
-    def _decode(self, x: BF, B: int, H: int, W: int) -> torch.Tensor:
-        # queries + per-view embedding (vat_lidar.py:259-270), broadcast over the batch
+    def _queries(self, B: int) -> torch.Tensor:
+        """queries + per-view embedding (vat_lidar.py:259-270), broadcast over the batch -> [B * nq, d] fp32."""
         ve = self.view_embed.detach().float().repeat_interleave(self.nq_per_view, dim=0).contiguous()
         q0 = ops.scale_add_rows(self.query.detach().float().contiguous(), ve)
-        q2 = q0.unsqueeze(0).expand(B, -1, -1).contiguous().view(B * self.n_queries, self.d_model)
+        return q0.unsqueeze(0).expand(B, -1, -1).contiguous().view(B * self.n_queries, self.d_model)
+
+    def _decode(self, x: BF, B: int, H: int, W: int) -> torch.Tensor:
+        q2 = self._queries(B)
         for blk in self.blocks:
             blk.precision = self.precision
             q2 = blk.forward_tokens(q2, x, B, self.n_queries, H * W)

@@ -213,6 +213,97 @@ def pillar_dwconv3x3_gelu(feat: torch.Tensor, coords: torch.Tensor, n_live: Opti
     return hi, lo
 
 
+# ---- sparse (tiled) BEV key stream: include/lvq.h "sparse BEV key stream of VATLiDAR" ----
+def pillar_index_map(coords: torch.Tensor, n_live: Optional[torch.Tensor], batch: int, ny: int, nx: int) -> torch.Tensor:
+    """[batch, ny, nx] int32: pillar row or -1 (PointPillarScatter as an index map)."""
+    F.require_cuda(coords, n_live)
+    idx = torch.empty((batch, ny, nx), dtype=torch.int32, device=coords.device)
+    rc = F.lib().lvq_pillar_index_map(F.ptr(coords), F.i64(coords.shape[0]), F.ptr(n_live), F.cint(batch), F.cint(ny), F.cint(nx), F.ptr(idx),
+                                      F.stream_ptr(coords.device))
+    F.check(rc, "lvq_pillar_index_map")
+    return idx
+
+
+_TILE_WS = {}
+
+
+def bev_tiles(idx: Optional[torch.Tensor], batch: int, ny: int, nx: int, device, force_all: bool = False):
+    """Tile bookkeeping -> (live_list [batch*nt] i32, tile_src [batch*nt] i32, counts [2] i32 = live tiles, live rows)."""
+    nt = (ny // 8) * (nx // 8)
+    live = torch.empty((batch * nt,), dtype=torch.int32, device=device)
+    src = torch.empty((batch * nt,), dtype=torch.int32, device=device)
+    counts = torch.empty((2,), dtype=torch.int32, device=device)
+    L = F.lib()
+    nbytes = int(L.lvq_bev_tiles_workspace_bytes(F.cint(batch), F.cint(ny), F.cint(nx)))
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _TILE_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _TILE_WS[key] = ws
+    rc = L.lvq_bev_tiles(F.ptr(idx), F.cint(batch), F.cint(ny), F.cint(nx), F.cint(1 if force_all else 0), F.ptr(live), F.ptr(src), F.ptr(counts),
+                         F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(device))
+    F.check(rc, "lvq_bev_tiles")
+    return live, src, counts
+
+
+def bev_tile_tokens(feat: torch.Tensor, idx: torch.Tensor, live: torch.Tensor, counts: torch.Tensor, cap_rows: int, batch: int, ny: int, nx: int,
+                    w9: torch.Tensor, b9: Optional[torch.Tensor], w: BF, bias, gamma, beta, eps: float, pe_tiled: torch.Tensor,
+                    out_lo: bool, tag: Optional[str] = None) -> BF:
+    """Fused refine conv -> proj -> LayerNorm -> + positional table over the live tiles -> x BF [cap_rows, n]."""
+    F.require_cuda(feat, idx, live, counts, w9, b9, pe_tiled)
+    n = w[0].shape[0]
+    xh, xl = _bf_empty((cap_rows, n), feat.device, out_lo)
+    with region(tag, feat.device):
+        rc = F.lib().lvq_bev_tile_tokens(F.ptr(feat), F.ptr(idx), F.ptr(live), F.ptr(counts), F.i64(batch * (ny // 8) * (nx // 8)), F.cint(batch),
+                                         F.cint(ny), F.cint(nx), F.cint(feat.shape[1]), F.ptr(w9), F.ptr(b9), F.ptr(w[0]), F.ptr(w[1]), F.ptr(bias),
+                                         F.ptr(gamma), F.ptr(beta), F.cfloat(eps), F.ptr(pe_tiled), F.cint(n), F.ptr(xh), F.ptr(xl),
+                                         F.stream_ptr(feat.device))
+    F.check(rc, "lvq_bev_tile_tokens")
+    return xh, xl
+
+
+def linear_live_rows(a: BF, w: BF, bias: Optional[torch.Tensor], rows_dev: torch.Tensor, w_rows, tag: Optional[str] = None) -> BF:
+    """a [cap, k] @ w[r0:r1].T + bias over the first *rows_dev rows (device-side count) -> BF [cap, n] (hi only unless a is split)."""
+    import ctypes
+    ah, al = a
+    wh, wl = w
+    cap, k = ah.shape
+    r0, r1 = w_rows
+    n = r1 - r0
+    ch, cl = _bf_empty((cap, n), ah.device, al is not None)
+    wo, bo = r0 * k * 2, r0 * 4
+    with region(tag, ah.device):
+        rc = F.lib().lvq_gemm_bf16_live_rows(F.ptr(ah), F.ptr(al), ctypes.c_void_p(wh.data_ptr() + wo),
+                                             ctypes.c_void_p(wl.data_ptr() + wo if wl is not None else 0),
+                                             ctypes.c_void_p(bias.data_ptr() + bo if bias is not None else 0), F.i64(cap), F.ptr(rows_dev), F.cint(n),
+                                             F.cint(k), F.i64(k), F.i64(k), F.i64(n), F.ptr(ch), F.ptr(cl), F.stream_ptr(ah.device))
+    F.check(rc, f"lvq_gemm_bf16_live_rows (cap={cap}, n={n}, k={k})")
+    return ch, cl
+
+
+def attention_tiled(q: BF, kv_live: torch.Tensor, kv_table: torch.Tensor, tile_src: torch.Tensor, *, batch: int, n_heads: int, nq: int,
+                    n_tiles: int, dh: int, scale: float, tag: Optional[str] = None) -> BF:
+    """q BF [batch*nq, d]; kv_live [cap, 2d] / kv_table [n_tiles*64, 2d] plain bf16 (K | V packed) -> BF [batch*nq, d]."""
+    qh, ql = q
+    dev = qh.device
+    d = n_heads * dh
+    oh, ol = _bf_empty((batch * nq, d), dev, ql is not None)
+    L = F.lib()
+    nbytes = int(L.lvq_attention_workspace_bytes(F.cint(batch), F.cint(n_heads), F.cint(nq), F.cint(n_tiles * 64), F.cint(dh), F.cint(1)))
+    key = (dev.index, "attn")
+    ws = _ATT_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _ATT_WS[key] = ws
+    with region(tag, dev):
+        rc = L.lvq_attention_bf16_tiled(F.ptr(qh), F.ptr(ql), F.ptr(kv_live), F.ptr(kv_live[:, d:]), F.ptr(kv_table), F.ptr(kv_table[:, d:]),
+                                        F.ptr(tile_src), F.cint(batch), F.cint(n_heads), F.cint(nq), F.cint(n_tiles), F.cint(dh), F.i64(nq * d),
+                                        F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.i64(nq * d), F.i64(d), F.i64(dh), F.cfloat(scale),
+                                        F.ptr(oh), F.ptr(ol), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
+    F.check(rc, f"lvq_attention_bf16_tiled (B={batch}, H={n_heads}, nq={nq}, tiles={n_tiles})")
+    return oh, ol
+
+
 def scale_add_rows(x: torch.Tensor, add: Optional[torch.Tensor], alpha: float = 1.0) -> torch.Tensor:
     F.require_cuda(x, add)
     rows, d = x.shape
