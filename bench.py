@@ -247,16 +247,23 @@ def main():
     per_step = cfg.n_layers + 1        # launches per step: n_layers (VATLiDAR, M = S*HW) + 1 (fusion block, M = S*196); keep the big ones
     big = [p for i, p in enumerate(events.get("ca_kv_proj", [])) if (i % per_step) < cfg.n_layers]
     kv_ms = avg_ms(big)
-    kv_flops = 2.0 * (S * h * w) * (2 * d) * d           # = 4*Nkv*d^2 per scene, x S scenes per launch
+    # rows the launch actually projects: the tiled key stream computes K|V for the LIVE tiles only (clean tiles come from the
+    # per-model table) -> EXECUTED rows, read back once after the timed region; the dense routes project every BEV cell
+    tc = getattr(pipe.vat_lidar, "_last_tile_counts", None)
+    live_rows = int(tc[1]) if tc is not None else S * h * w
+    kv_rows = (live_rows + 255) // 256 * 256             # whole 256-row tiles run
+    kv_flops = 2.0 * kv_rows * (2 * d) * d               # 4 d^2 per projected key
     form = {"bf16": "plain operands: 1 MFMA pass", "mixed": "A plain, W hi+lo: 2 MFMA passes (executed FLOPs = 2x algorithmic)",
             "bf16x3": "A and W hi+lo: 3 MFMA passes (executed FLOPs = 3x algorithmic)"}[args.precision]
     roofline = None
     if kv_ms:
         ach = kv_flops / (kv_ms * 1e-3) / 1e12
-        tr, src = profile_traffic([f"k_gemm_256 M={S * h * w} N={2 * d} K={d} {args.precision}"])
-        roofline = {"bound": "mfma", "kernel": "k_gemm_256 (256x256 tile, LDS-DMA, A ring 3 / W ring 2; VATLiDAR.ca K|V projection, M=S*HW, N=2d, K=d); " + form,
+        tr, src = profile_traffic([f"k_gemm_256 M={kv_rows} N={2 * d} K={d} {args.precision}"])
+        roofline = {"bound": "mfma", "kernel": "k_gemm_256 (256x256 tile, LDS-DMA, A ring 3 / W ring 2; VATLiDAR.ca K|V projection over the live key tiles, "
+                    f"M = {kv_rows} of {S * h * w} BEV cells, N=2d, K=d); " + form,
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "traffic": tr, "traffic_source": src, "avg_launch_ms": round(kv_ms, 4), "flops_per_launch": kv_flops,
+                    "rows_projected": kv_rows, "rows_dense": S * h * w, "live_tile_fraction": round(live_rows / float(S * h * w), 4),
                     "executed_flops_per_launch": kv_flops * {"bf16": 1, "mixed": 2, "bf16x3": 3}[args.precision]}
 
     result = {
