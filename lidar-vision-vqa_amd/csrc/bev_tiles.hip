@@ -156,18 +156,15 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
     }
     const int col0 = 16 * J * wid + 4 * J * g4;                  // this lane's first column (4 J consecutive ones)
 
-    // work order: 8 consecutive list entries (same positional tile, different scenes) go to workgroups of one XCD (ids 8 apart)
-    auto entry_of = [&](int64_t v) -> int64_t {
-        const int64_t grp = v >> 6;
-        const int within = (int)(v & 63);
-        return grp * 64 + (within & 7) * 8 + (within >> 3);
-    };
-    const int64_t n_pad = ((int64_t)n_live + 63) / 64 * 64;
+    // work order: every workgroup takes one CONTIGUOUS run of the (tile, scene)-ordered list, so the scenes that share a positional
+    // table tile (196 KB of fp32) are served back to back by the same workgroup: the first read of the tile comes from HBM, the
+    // repeats hit the XCD's L2 (with the runs dealt round-robin all sharers missed at once and every group of 16 cells paid an HBM
+    // round trip: 21 us per tile)
+    const int64_t chunk = ((int64_t)n_live + gridDim.x - 1) / gridDim.x;
+    const int64_t k_begin = (int64_t)blockIdx.x * chunk, k_end = k_begin + chunk < n_live ? k_begin + chunk : n_live;
     auto tile_at = [&](int64_t it, int &s, int &t, int64_t &k) -> bool {      // it-th tile of this workgroup
-        const int64_t v = (int64_t)blockIdx.x + it * gridDim.x;
-        if (v >= n_pad) return false;
-        k = entry_of(v);
-        if (k >= n_live) { s = -1; t = 0; return true; }                       // padding slot of the permutation: nothing to do
+        k = k_begin + it;
+        if (k >= k_end) return false;
         const int code = a.live_list[k];
         t = code / a.S; s = code - t * a.S;
         return true;
@@ -417,7 +414,6 @@ template <int J> static int launch_tile_tokens(const bt::TokArgs &a, bool x3, bo
         return LVQ_ELAUNCH;
     int64_t grid = (int64_t)lvq_cu_count();
     if (grid > cap_tiles) grid = cap_tiles;
-    grid = (grid + 7) / 8 * 8;                                     // whole groups of 8 (the XCD-aware entry order)
     if (x3 && olo) hipLaunchKernelGGL((bt::k_tile_tokens<J, true, true>), dim3((unsigned)grid), dim3(512), lds, st, a);
     else if (x3)   hipLaunchKernelGGL((bt::k_tile_tokens<J, true, false>), dim3((unsigned)grid), dim3(512), lds, st, a);
     else           hipLaunchKernelGGL((bt::k_tile_tokens<J, false, false>), dim3((unsigned)grid), dim3(512), lds, st, a);
