@@ -37,6 +37,11 @@ int lvq_binned_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t
                              int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes,
                              hipStream_t st);
 
+// key-contiguous slabs, single binning pass + look-back ranks (voxel_dyn.hip): the default dynamic path
+size_t lvq_dyn2_workspace_bytes(int64_t n, int64_t keyspace);
+int lvq_dyn2_voxelize(const float *pts, int64_t n, int c, int batch_size, const float *range_host, const float *vsize_host,
+                      const int32_t *grid_host, int ndim, int32_t *unq_inv, int32_t *pt_coords, int32_t *unq_key, int32_t *unq_cnt,
+                      int32_t *coords_bzyx, int32_t *counts, void *ws, size_t ws_bytes, hipStream_t st);
 // hash-balanced slabs + input-order placement (voxel_hashed.hip): the default hard path
 size_t lvq_hashed_hard_workspace_bytes(int64_t n, int n_scenes);
 int lvq_hashed_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n, int n_scenes, int c, const float *range_host,
@@ -682,8 +687,9 @@ extern "C" size_t lvq_voxelize_dynamic_workspace_bytes(int64_t n_points, int bat
     SizerAdapter a;
     DynWs w;
     dyn_layout(a, w, n_points, ks);
-    const size_t binned = lvq_binned_dynamic_workspace_bytes(n_points);
-    return a.s.total() > binned ? a.s.total() : binned;
+    const size_t binned = lvq_binned_dynamic_workspace_bytes(n_points), dyn2 = lvq_dyn2_workspace_bytes(n_points, ks);
+    size_t need = a.s.total() > binned ? a.s.total() : binned;
+    return need > dyn2 ? need : dyn2;
 }
 
 extern "C" int lvq_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_size, const float *range_host,
@@ -705,7 +711,12 @@ extern "C" int lvq_voxelize_dynamic(const float *pts, int64_t n, int c, int batc
     }
     if (!pts || !unq_inv || !unq_key || !unq_cnt || !coords_bzyx) return LVQ_EINVAL;
     if (!ws || ws_bytes < lvq_voxelize_dynamic_workspace_bytes(n, batch_size, grid_host, ndim)) return LVQ_EWORKSPACE;
-    if (getenv("LVQ_VOXEL_LEGACY") == nullptr) {       // slab-binned path first; the two-level-bitmap kernels below are the fallback
+    if (getenv("LVQ_VOXEL_LEGACY") == nullptr && getenv("LVQ_VOXEL_BINNED") == nullptr) {      // default: voxel_dyn.hip
+        const int rc = lvq_dyn2_voxelize(pts, n, c, batch_size, range_host, vsize_host, grid_host, ndim, unq_inv, pt_coords, unq_key, unq_cnt,
+                                         coords_bzyx, counts, ws, ws_bytes, st);
+        if (rc != LVQ_EUNSUPPORTED) return rc;
+    }
+    if (getenv("LVQ_VOXEL_LEGACY") == nullptr) {       // slab-binned path (4 kernels); the two-level-bitmap kernels below are the last fallback
         const int rc = lvq_binned_voxelize_dynamic(pts, n, c, batch_size, range_host, vsize_host, grid_host, ndim, unq_inv, pt_coords,
                                                    unq_key, unq_cnt, coords_bzyx, counts, ws, ws_bytes, st);
         if (rc != LVQ_EUNSUPPORTED) return rc;

@@ -239,12 +239,14 @@ def test_hard_voxelizer_workspace_one_byte_short_is_refused(mean):
     assert bool((bufs["svo"].view(torch.uint8, (-1,)) == PATTERN).all())
 
 
-@pytest.mark.parametrize("legacy", [False, True])
+@pytest.mark.parametrize("path", ["lookback", "binned", "legacy"])
 @pytest.mark.parametrize("case", list(GUARD_CASES))
 @pytest.mark.parametrize("ndim,vs", [(3, synth.VOXEL_01), (2, synth.VOXEL_PILLAR)])
-def test_dynamic_voxelizer_guard_bands(case, ndim, vs, legacy, monkeypatch):
-    if legacy:
-        monkeypatch.setenv("LVQ_VOXEL_LEGACY", "1")
+def test_dynamic_voxelizer_guard_bands(case, ndim, vs, path, monkeypatch):
+    legacy = path
+    env = {"binned": "LVQ_VOXEL_BINNED", "legacy": "LVQ_VOXEL_LEGACY"}.get(path)
+    if env:
+        monkeypatch.setenv(env, "1")
     lib = F.lib()
     scenes = [s for s in GUARD_CASES[case]()]
     bs = len(scenes)
