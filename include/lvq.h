@@ -301,7 +301,8 @@ int lvq_rope_inplace_at(lvq_bf16 *x, lvq_bf16 *x_lo, int64_t rows, int seq_len, 
 int lvq_argmax_rows(const float *x, int64_t rows, int n, int64_t *out_idx, lvq_stream_t stream);
 /* e   payload of the per-step all-reduce (training/utils/distributed.py:7-26, commu_utils.py:148-168): out[c] = sum over rows of
  * x[r, c], fp32, in a fixed (run-to-run identical) order.  rows = 0 gives zeros. */
-int lvq_colsum(const float *x, int64_t rows, int d, float *out, lvq_stream_t stream);
+size_t lvq_colsum_workspace_bytes(int64_t rows, int d);
+int lvq_colsum(const float *x, int64_t rows, int d, float *out, void *ws, size_t ws_bytes, lvq_stream_t stream);
 /* f4  one sampling step of `base_model.generate(do_sample=True, temperature=, top_k=, top_p=)` (the reference's default call,
  * inference_engine.py:236-240,283-296 -> transformers' TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper, softmax,
  * multinomial): out_idx[r] ~ softmax(logits[r] / temperature) restricted to the top_k largest logits (ties kept) and then to

@@ -34,7 +34,10 @@ constexpr int TS = 8, TCELLS = 64, HALO = 10, NHALO = 100;
 __global__ void __launch_bounds__(256) k_tile_flags(const int32_t *__restrict__ idx, int S, int H, int W, int force, uint8_t *__restrict__ flags) {
     const int tw = W / TS, th = H / TS, nt = tw * th;
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= (int64_t)S * nt) return;
+    if (g >= (int64_t)S * nt) {
+        if (g < (int64_t)S * nt + 16 * 1024 + 64) flags[g] = 0;                // padding read by k_tile_compact's 16-byte loads
+        return;
+    }
     const int s = (int)(g / nt), t = (int)(g % nt);
     bool live = force != 0;
     if (!live) {
@@ -60,11 +63,14 @@ __global__ void __launch_bounds__(1024) k_tile_compact(const uint8_t *__restrict
                                                       int32_t *__restrict__ tile_src, int32_t *__restrict__ counts) {
     __shared__ int wave_tot[16];
     const int64_t total = (int64_t)S * nt;
-    const int per = (int)((total + 1023) / 1024);
+    const int per = (int)(((total + 1023) / 1024 + 15) / 16 * 16);      // flags per thread, whole 16-byte words (the buffer is padded)
     const int64_t b0 = (int64_t)threadIdx.x * per;
     int c = 0;
-    for (int j = 0; j < per; ++j)
-        if (b0 + j < total) c += flags[b0 + j];
+    for (int j = 0; j < per; j += 16) {
+        if (b0 + j >= total) break;
+        const uint4 v = *reinterpret_cast<const uint4 *>(flags + b0 + j);       // bytes past `total` are zero (k_tile_flags pads)
+        c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);            // flags are 0 / 1
+    }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int incl = c;
 #pragma unroll
@@ -388,7 +394,7 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
 // =================================================================================================
 extern "C" size_t lvq_bev_tiles_workspace_bytes(int batch, int ny, int nx) {
     if (batch <= 0 || ny <= 0 || nx <= 0) return 0;
-    return lvq_align((size_t)batch * (ny / 8) * (nx / 8)) + 512;          // one flag byte per (tile, scene)
+    return lvq_align((size_t)batch * (ny / 8) * (nx / 8) + 16 * 1024 + 64) + 512;          // one flag byte per (tile, scene) + zero padding
 }
 
 extern "C" int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, int force_all, int32_t *live_list, int32_t *tile_src,
@@ -400,7 +406,7 @@ extern "C" int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, 
     if (!ws || ws_bytes < lvq_bev_tiles_workspace_bytes(batch, ny, nx)) return LVQ_EWORKSPACE;
     uint8_t *flags = (uint8_t *)ws;
     hipStream_t st = lvq_s(stream);
-    hipLaunchKernelGGL(bt::k_tile_flags, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, flags);
+    hipLaunchKernelGGL(bt::k_tile_flags, dim3((unsigned)lvq_cdiv(total + 16 * 1024 + 64, 256)), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, flags);
     hipLaunchKernelGGL(bt::k_tile_compact, dim3(1), dim3(1024), 0, st, flags, batch, (int)nt, live_list, tile_src, counts);
     return lvq_launch_status();
 }

@@ -100,7 +100,10 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_bf16(GemmArgs g) {
     // into a private-memory lookup table by the optimiser
     const int64_t dA1 = g.a[1] - g.a[0], dA2 = g.a[2] - g.a[0], dW1 = g.w[1] - g.w[0], dW2 = g.w[2] - g.w[0];
     auto gload = [&](int it) __attribute__((always_inline)) {
-        const int seg = it / nk, k0 = (it - seg * nk) * BK;
+        // K tiles run k-major, segment-minor: the hi and lo passes over one K tile are adjacent, so an operand that is the same in
+        // two segments (A in the x2w form, A / W in bf16x3) is re-read while it is still in L2 (segment-major order streamed A
+        // from HBM once per segment: 33.6 GB read for 7.3 GB of A on the live-row K|V projection, PMC FETCH_SIZE)
+        const int kt = it / g.nseg, seg = it - kt * g.nseg, k0 = kt * BK;
         const uint16_t *A = (g.a[0] + (seg == 0 ? (int64_t)0 : seg == 1 ? dA1 : dA2)) + z * g.a_bs;
         const uint16_t *W = (g.w[0] + (seg == 0 ? (int64_t)0 : seg == 1 ? dW1 : dW2)) + z * g.w_bs;
 #pragma unroll
@@ -140,8 +143,7 @@ __global__ void __launch_bounds__(NW * 64) k_gemm_bf16(GemmArgs g) {
     int d_seg = 0, d_k0 = 0;
     auto stage_dma = [&](int /*it*/, int buf) __attribute__((always_inline)) {
         const int seg = d_seg, k0 = d_k0;
-        d_k0 += BK;
-        if (d_k0 >= nk * BK) { d_k0 = 0; ++d_seg; }
+        if (++d_seg >= g.nseg) { d_seg = 0; d_k0 += BK; }
         const uint16_t *A = (g.a[0] + (seg == 0 ? (int64_t)0 : seg == 1 ? dA1 : dA2)) + z * g.a_bs;
         const uint16_t *W = (g.w[0] + (seg == 0 ? (int64_t)0 : seg == 1 ? dW1 : dW2)) + z * g.w_bs;
         uint8_t *sa = smem + buf * STAGE, *sb = sa + BM * 128;
@@ -529,14 +531,12 @@ __global__ void __launch_bounds__(512) k_gemm_256(GemmArgs g) {
     // waves back-pressures the VMEM issue port and holds up the LDS reads + MFMAs queued behind it)
     auto a_next = [&]() __attribute__((always_inline)) -> const uint16_t * {
         const uint16_t *A = pa + (a_seg == 0 ? (int64_t)0 : a_seg == 1 ? dA1 : dA2) + a_k0;
-        a_k0 += BK;
-        if (a_k0 >= nk * BK) { a_k0 = 0; ++a_seg; }
+        if (++a_seg >= g.nseg) { a_seg = 0; a_k0 += BK; }      // k-major, segment-minor (see k_gemm_bf16::gload)
         return A;
     };
     auto w_next = [&]() __attribute__((always_inline)) -> const uint16_t * {
         const uint16_t *W = pw + (w_seg == 0 ? (int64_t)0 : w_seg == 1 ? dW1 : dW2) + w_k0;
-        w_k0 += BK;
-        if (w_k0 >= nk * BK) { w_k0 = 0; ++w_seg; }
+        if (++w_seg >= g.nseg) { w_seg = 0; w_k0 += BK; }
         return W;
     };
     auto a_piece = [&](const uint16_t *A, int slot, int i) __attribute__((always_inline)) {
@@ -718,7 +718,7 @@ __global__ void __launch_bounds__(256, (NT16 <= 48 ? 2 : 1)) k_gemm_ln(GemmLnArg
     for (int j = 0; j < NT16; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int it = 0; it < nk * g.nseg; ++it) {
-        const int seg = it / nk, k0 = (it - seg * nk) * 32;
+        const int kt = it / g.nseg, seg = it - kt * g.nseg, k0 = kt * 32;
         const uint16_t *A = g.a[seg], *W = g.w[seg];
         // stage W[:, k0:k0+32] (N rows x 4 chunks) and A[m0:m0+64, k0:k0+32]
         // N*4 chunks / 256 threads = NT16/4 per thread, issued in batches of 4 independent loads before the LDS writes

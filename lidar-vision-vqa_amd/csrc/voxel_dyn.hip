@@ -26,9 +26,9 @@ struct Geom {
 };
 
 constexpr int MAX_SLABS = 8192;
-constexpr int DCAP = 2048;              // entries of a slab's fixed region (mean fill ~400: Dist-C's densest 0.64 m strips hold ~800)
+constexpr int DCAP = 4096;              // entries of a slab's fixed region (mean fill <= ~800; Dist-C's densest 1.3 m strips hold ~1600)
 constexpr int BIN_NT = 1024, BIN_PPT = 4;
-constexpr int SLAB_NT = 256;
+constexpr int SLAB_NT = 512;
 constexpr int VCAP = 2048;              // voxels of a slab counted in LDS (more: global atomics on unq_cnt)
 constexpr uint32_t ST_AGG = 1u << 30, ST_PRE = 2u << 30, ST_MASK = 3u << 30, VAL_MASK = ~ST_MASK;
 
@@ -52,13 +52,14 @@ struct SizerAdapter {
     template <typename T> T *take(size_t n) { s.template take<T>(n); return nullptr; }
 };
 
-// slab geometry: 2^logslab keys per slab, bitmap <= 32 KiB of LDS (logslab <= 18), ~<= 512 points per slab on average
+// slab geometry: 2^logslab keys per slab, bitmap <= 64 KiB of LDS (logslab <= 19), ~800 points per slab on average: the binning
+// pass pays one global atomic per (block, slab), so fewer, larger slabs (first version: 1280 slabs of ~410 points, 30 us of binning)
 static bool choose(int64_t keyspace, int64_t n, int &logslab, int &nslabs) {
     if (keyspace <= 0 || keyspace >= (1ll << 31)) return false;
-    int64_t want = n / 384 + 1;
+    int64_t want = n / 800 + 1;
     if (want > MAX_SLABS) want = MAX_SLABS;
     int ls = 10;
-    while (ls < 18 && ((keyspace + (1ll << ls) - 1) >> ls) > want) ++ls;
+    while (ls < 19 && ((keyspace + (1ll << ls) - 1) >> ls) > want) ++ls;
     if (((keyspace + (1ll << ls) - 1) >> ls) > MAX_SLABS) return false;
     logslab = ls;
     nslabs = (int)((keyspace + (1ll << ls) - 1) >> ls);
@@ -203,21 +204,31 @@ __global__ void __launch_bounds__(SLAB_NT) k_dslab(Geom g, int ndim, int logslab
     }
     // ---- publish this slab's voxel count, look back for the base (decoupled look-back: the words carry their own payload, so
     // relaxed agent-scope atomics are all the protocol needs) ----
-    if (tid == 0) {
-        __hip_atomic_store(&w.lookback[s], ST_AGG | (uint32_t)nvox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // The first version walked back one slab at a time from one lane: with every workgroup in flight nobody has a prefix yet, so
+    // slab s read s words one dependent L2 round trip after the other (104 us for 1280 slabs).  Here wave 0 reads 64 predecessors
+    // per step and stops at the nearest published prefix.
+    if (wid == 0) {
+        if (lane == 0) __hip_atomic_store(&w.lookback[s], ST_AGG | (uint32_t)nvox, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int base = 0;
-        for (int q = s - 1; q >= 0; --q) {
-            uint32_t v;
-            do {
-                v = __hip_atomic_load(&w.lookback[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!(v & ST_MASK)) __builtin_amdgcn_s_sleep(2);
-            } while (!(v & ST_MASK));
-            base += (int)(v & VAL_MASK);
-            if ((v & ST_MASK) == ST_PRE) break;                 // predecessor's inclusive prefix: done
+        for (int q0 = s - 1; q0 >= 0;) {
+            const int q = q0 - lane;
+            const uint32_t v = q >= 0 ? __hip_atomic_load(&w.lookback[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ST_PRE;   // before slab 0: prefix 0
+            const unsigned long long ready = __ballot((v & ST_MASK) != 0u), pre = __ballot((v & ST_MASK) == ST_PRE);
+            const int p = pre ? __builtin_ctzll(pre) : 64;                      // nearest predecessor that already holds a prefix
+            const unsigned long long need = p >= 63 ? ~0ull : ((1ull << (p + 1)) - 1ull);
+            if ((ready & need) != need) { __builtin_amdgcn_s_sleep(1); continue; }   // somebody in the window has not published yet
+            int part = lane <= p ? (int)(v & VAL_MASK) : 0;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+            base += part;
+            if (p < 64) break;
+            q0 -= 64;
         }
-        __hip_atomic_store(&w.lookback[s], ST_PRE | (uint32_t)(base + nvox), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        l_base = base;
-        if (s == nslabs - 1) { counts[0] = base + nvox; counts[1] = w.misc[2]; }
+        if (lane == 0) {
+            __hip_atomic_store(&w.lookback[s], ST_PRE | (uint32_t)(base + nvox), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            l_base = base;
+            if (s == nslabs - 1) { counts[0] = base + nvox; counts[1] = w.misc[2]; }
+        }
     }
     const bool vfit = nvox <= VCAP;
     if (vfit) for (int v = tid; v < nvox; v += SLAB_NT) lcnt[v] = 0;
@@ -300,6 +311,8 @@ int lvq_dyn2_voxelize(const float *pts, int64_t n, int c, int batch_size, const 
                        pt_coords, unq_inv);
     const int nw = 1 << (logslab - 6);
     const size_t lds = (sizeof(unsigned long long) + sizeof(int32_t)) * nw + sizeof(int32_t) * VCAP;
+    static LvqLdsOnce once;
+    if (lds > 64 * 1024 && !lvq_ensure_lds(once, {(const void *)k_dslab}, 112 * 1024)) return LVQ_ELAUNCH;
     hipLaunchKernelGGL(k_dslab, dim3(nslabs), dim3(SLAB_NT), lds, st, g, ndim, logslab, nslabs, w, unq_inv, unq_key, unq_cnt, coords_bzyx, counts);
     return lvq_launch_status();
 }

@@ -64,6 +64,9 @@ def max_over_ranks(x: float, device=None) -> float:
     return float(t.item())
 
 
+_COLSUM_WS = {}
+
+
 def reduce_step(per_scene: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
     """Fill buf = [sum over scenes and tokens of per_scene (d) | n_scenes] and all-reduce(SUM) it once.
     per_scene [S, n, d] (fused tokens, or answer logits once the head is attached).  After the call
@@ -73,7 +76,12 @@ def reduce_step(per_scene: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
         from . import _ffi as F                      # HIP path: column sums in a fixed order (lvq_colsum), count slot by fill
         x = per_scene.reshape(-1, per_scene.shape[-1])
         F.require_cuda(x, buf)
-        F.check(F.lib().lvq_colsum(F.ptr(x), F.i64(x.shape[0]), F.cint(x.shape[1]), F.ptr(buf), F.stream_ptr(x.device)), "lvq_colsum")
+        nbytes = int(F.lib().lvq_colsum_workspace_bytes(F.i64(x.shape[0]), F.cint(x.shape[1])))
+        ws = _COLSUM_WS.get(x.device)
+        if ws is None or ws.numel() < nbytes:
+            ws = _COLSUM_WS[x.device] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        F.check(F.lib().lvq_colsum(F.ptr(x), F.i64(x.shape[0]), F.cint(x.shape[1]), F.ptr(buf), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(x.device)),
+                "lvq_colsum")
         buf[-1:].fill_(float(S))
     else:                                            # gloo rehearsal on CPU tensors (tests/test_dist.py)
         buf[:-1] = per_scene.sum(dim=(0, 1))
