@@ -37,11 +37,6 @@ int lvq_binned_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t
                              int32_t *coords_bzyx, int32_t *num_pts, int32_t *scene_voxel_off, void *ws, size_t ws_bytes,
                              hipStream_t st);
 
-// key-contiguous slabs, single binning pass + look-back ranks (voxel_dyn.hip): the default dynamic path
-size_t lvq_dyn2_workspace_bytes(int64_t n, int64_t keyspace);
-int lvq_dyn2_voxelize(const float *pts, int64_t n, int c, int batch_size, const float *range_host, const float *vsize_host,
-                      const int32_t *grid_host, int ndim, int32_t *unq_inv, int32_t *pt_coords, int32_t *unq_key, int32_t *unq_cnt,
-                      int32_t *coords_bzyx, int32_t *counts, void *ws, size_t ws_bytes, hipStream_t st);
 // hash-balanced slabs + input-order placement (voxel_hashed.hip): the default hard path
 size_t lvq_hashed_hard_workspace_bytes(int64_t n, int n_scenes);
 int lvq_hashed_voxelize_hard(const float *pts, const int32_t *scene_off, int64_t n, int n_scenes, int c, const float *range_host,
@@ -687,9 +682,8 @@ extern "C" size_t lvq_voxelize_dynamic_workspace_bytes(int64_t n_points, int bat
     SizerAdapter a;
     DynWs w;
     dyn_layout(a, w, n_points, ks);
-    const size_t binned = lvq_binned_dynamic_workspace_bytes(n_points), dyn2 = lvq_dyn2_workspace_bytes(n_points, ks);
-    size_t need = a.s.total() > binned ? a.s.total() : binned;
-    return need > dyn2 ? need : dyn2;
+    const size_t binned = lvq_binned_dynamic_workspace_bytes(n_points);
+    return a.s.total() > binned ? a.s.total() : binned;
 }
 
 extern "C" int lvq_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_size, const float *range_host,
@@ -711,12 +705,13 @@ extern "C" int lvq_voxelize_dynamic(const float *pts, int64_t n, int c, int batc
     }
     if (!pts || !unq_inv || !unq_key || !unq_cnt || !coords_bzyx) return LVQ_EINVAL;
     if (!ws || ws_bytes < lvq_voxelize_dynamic_workspace_bytes(n, batch_size, grid_host, ndim)) return LVQ_EWORKSPACE;
-    if (getenv("LVQ_VOXEL_LEGACY") == nullptr && getenv("LVQ_VOXEL_BINNED") == nullptr) {      // default: voxel_dyn.hip
-        const int rc = lvq_dyn2_voxelize(pts, n, c, batch_size, range_host, vsize_host, grid_host, ndim, unq_inv, pt_coords, unq_key, unq_cnt,
-                                         coords_bzyx, counts, ws, ws_bytes, st);
-        if (rc != LVQ_EUNSUPPORTED) return rc;
-    }
-    if (getenv("LVQ_VOXEL_LEGACY") == nullptr) {       // slab-binned path (4 kernels); the two-level-bitmap kernels below are the last fallback
+    // Measured dead end (round 2): one binning pass into fixed key-contiguous slab regions + ONE slab kernel that takes its global
+    // rank offset from a decoupled look-back over the earlier slabs (memset + 2 kernels instead of memset + 4).  Bit-exact, but
+    // 132 us against 87 us for the path below at 8 x 65 536 points: the slab workgroup became a chain of six latency-bound phases
+    // (bitmap 4.5 us, scan 2.3, look-back 6.8, inverse map 15, keys / counts / coords 13 per workgroup at one 64-KiB-bitmap workgroup
+    // per CU, 2.5 rounds), and smaller slabs give the time back to the binning pass (one global atomic per block and slab: 30 us at
+    // 1280 slabs).  The four-kernel form keeps 4 slab workgroups per CU in flight.
+    if (getenv("LVQ_VOXEL_LEGACY") == nullptr) {       // slab-binned path first; the two-level-bitmap kernels below are the fallback
         const int rc = lvq_binned_voxelize_dynamic(pts, n, c, batch_size, range_host, vsize_host, grid_host, ndim, unq_inv, pt_coords,
                                                    unq_key, unq_cnt, coords_bzyx, counts, ws, ws_bytes, st);
         if (rc != LVQ_EUNSUPPORTED) return rc;

@@ -239,7 +239,7 @@ def test_hard_voxelizer_workspace_one_byte_short_is_refused(mean):
     assert bool((bufs["svo"].view(torch.uint8, (-1,)) == PATTERN).all())
 
 
-@pytest.mark.parametrize("path", ["lookback", "binned", "legacy"])
+@pytest.mark.parametrize("path", ["binned", "legacy"])
 @pytest.mark.parametrize("case", list(GUARD_CASES))
 @pytest.mark.parametrize("ndim,vs", [(3, synth.VOXEL_01), (2, synth.VOXEL_PILLAR)])
 def test_dynamic_voxelizer_guard_bands(case, ndim, vs, path, monkeypatch):
