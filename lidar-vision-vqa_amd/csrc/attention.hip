@@ -728,9 +728,9 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
         const uint32_t e0 = vb + vlane[0][0], e1 = vb + vlane[0][1], o0 = vb + vlane[1][0], o1 = vb + vlane[1][1];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16 sc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sc[i] = -mref;
+            // scores straight from a ZERO accumulator (an inline constant of the MFMA: no 16 v_mov per block): the fast stream uses
+            // the fixed softmax reference 0, i.e. P = 2^score
+            f32x16 sc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + (kb * 32 + l31) * KROW + (((2 * ks + hi) ^ fk) << 3));
@@ -785,12 +785,13 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
         slot = slot == 2 ? 0 : slot + 1;
     };
 
-    // The online-softmax reference mref is set by the first tile and then never moved: fp32 O / l and bf16 P keep their relative
-    // precision whatever the exponent, so the only hazard is overflow when a later score exceeds the first tile's maximum by
-    // ~2^100 -- which is detected at the end (row sum above 2^100 or not finite) and answered by running the stream again in the
-    // classic form (maximum tracked and O rescaled every tile).  The steady-state loop therefore has no row maximum, no branch
-    // and no rescale: a rescale inside it, even behind a never-taken branch, made the compiler copy the 32 accumulator
-    // registers every tile, and the 17-step v_max3 chain sat between the score MFMAs and the first exp.
+    // The fast stream uses the FIXED softmax reference 0 (P = 2^score in the log2 domain): fp32 O / l and bf16 P keep their
+    // relative precision whatever the exponent, so the only hazards are overflow (a score above ~100) and total underflow (every
+    // score of a row below ~-100) -- both detected at the end (row sum outside [2^-100, 2^100] or not finite) and answered by
+    // running the stream again in the classic form (first tile sets the reference, maximum tracked, O rescaled).  The steady-state
+    // loop therefore has no row maximum, no branch, no rescale and no accumulator initialisation: a rescale inside it, even behind
+    // a never-taken branch, made the compiler copy the 32 accumulator registers every tile, and the 17-step v_max3 chain sat
+    // between the score MFMAs and the first exp.
     uint32_t *redo_flag = reinterpret_cast<uint32_t *>(smem + 3 * TILE_E);
     auto stream = [&](auto slow_tag) __attribute__((always_inline)) {
         constexpr bool SLOW = decltype(slow_tag)::value;
@@ -806,7 +807,7 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
         }
         __builtin_amdgcn_s_barrier();
         int t = t0;
-        if (t < t1) {                                          // first tile: absolute scores set the reference
+        if (SLOW && t < t1) {                                  // classic form, first tile: absolute scores set the reference
             f32x16 sc[2];
             pre(t);
             scores(smem, 0.f, sc);
@@ -851,10 +852,11 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
     };
     if (tid == 0) *redo_flag = 0;
     stream(std::false_type{});
-    {
+    fresh = !(t0 < t1);
+    if (t0 < t1) {
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
         const float ltot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-        if (!(ltot < 1.2676506e30f)) *redo_flag = 1;           // 2^100; also catches inf / NaN
+        if (!(ltot < 1.2676506e30f) || !(ltot > 7.8886091e-31f)) *redo_flag = 1;      // outside [2^-100, 2^100]; also catches inf / NaN
     }
     __syncthreads();
     if (*redo_flag) {                                          // workgroup-uniform

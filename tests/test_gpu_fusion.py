@@ -497,3 +497,35 @@ def test_vat_lidar_golden_mixed(name):
     with torch.no_grad():
         out = m(dev(synth.randn((c["B"], c["c_in"], c["H"], c["W"]), c["seed"] + 1000)))
     check_golden(out, golden("vat_lidar_" + name), "bf16x3")
+
+
+@pytest.mark.parametrize("shift", [-40.0, 40.0, -6.0])
+def test_attention_long_stream_extreme_logit_offsets(shift):
+    """k_attn32's fast stream takes 2^score with the fixed reference 0: rows whose scores ALL sit far below zero (total underflow of
+    the row sum) or far above it (overflow) must trigger the classic re-run and still match the reference; a moderate offset
+    (-6 in the logit domain) stays on the fast stream."""
+    o = ops()
+    B, H, nq, nkv, dh = 1, 2, 192, 4096, 64
+    g = torch.Generator().manual_seed(17)
+    q = torch.randn(B, nq, H, dh, generator=g)
+    k = torch.randn(B, nkv, H, dh, generator=g) * 0.5
+    # add `shift` to every logit of a row: k += shift * sqrt(dh) * q_unit / |q| is row dependent, so use a constant direction instead
+    u = torch.zeros(dh); u[0] = 1.0
+    q = q + 8.0 * u                                    # every query has a large component along u ...
+    k = k + (shift * math.sqrt(dh) / 8.0) * u          # ... so k's component along u shifts all logits by ~shift * (1 + noise)
+    q, k = bf_round(q).to(DEV), bf_round(k).to(DEV)
+    v = bf_round(torch.randn(B, nkv, H, dh, generator=g)).to(DEV)
+    qb, kb, vb = (o.cast(t.reshape(-1, H * dh), False) for t in (q, k, v))
+    st = lambda n: (n * H * dh, H * dh, dh)
+    out = o.attention(qb, kb, vb, batch=B, n_heads=H, n_kv_heads=H, nq=nq, nkv=nkv, dh=dh, q_strides=st(nq), k_strides=st(nkv),
+                      v_strides=st(nkv), scale=1.0 / math.sqrt(dh))
+    got = o.to_f32(out).double().cpu().view(B, nq, H, dh)
+    c = torch.tensor(1.0 / math.sqrt(dh), dtype=torch.float32) * torch.tensor(1.4426950408889634, dtype=torch.float32)
+    qs = bf_round(q.cpu() * c)
+    qd, kd, vd = (t.double().cpu().transpose(1, 2) for t in (qs, k, v))
+    lg = qd @ kd.transpose(-1, -2)
+    assert (shift < -30 and float(lg.max(-1).values.max()) < -110) or (shift > 30 and float(lg.max()) > 110) or abs(shift) < 30
+    wgt = torch.exp2(lg - lg.max(-1, keepdim=True).values)
+    ref = ((wgt / wgt.sum(-1, keepdim=True)) @ vd).transpose(1, 2)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 3e-2
