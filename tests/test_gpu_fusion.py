@@ -499,7 +499,7 @@ def test_vat_lidar_golden_mixed(name):
     check_golden(out, golden("vat_lidar_" + name), "bf16x3")
 
 
-@pytest.mark.parametrize("shift", [-40.0, 40.0, -6.0])
+@pytest.mark.parametrize("shift", [-100.0, 100.0, -6.0])
 def test_attention_long_stream_extreme_logit_offsets(shift):
     """k_attn32's fast stream takes 2^score with the fixed reference 0: rows whose scores ALL sit far below zero (total underflow of
     the row sum) or far above it (overflow) must trigger the classic re-run and still match the reference; a moderate offset
@@ -524,7 +524,8 @@ def test_attention_long_stream_extreme_logit_offsets(shift):
     qs = bf_round(q.cpu() * c)
     qd, kd, vd = (t.double().cpu().transpose(1, 2) for t in (qs, k, v))
     lg = qd @ kd.transpose(-1, -2)
-    assert (shift < -30 and float(lg.max(-1).values.max()) < -110) or (shift > 30 and float(lg.max()) > 110) or abs(shift) < 30
+    rmax = lg.max(-1).values
+    assert (shift < -30 and float(rmax.median()) < -110) or (shift > 30 and float(rmax.median()) > 110) or abs(shift) < 30   # most rows leave the fast stream's range
     wgt = torch.exp2(lg - lg.max(-1, keepdim=True).values)
     ref = ((wgt / wgt.sum(-1, keepdim=True)) @ vd).transpose(1, 2)
     assert torch.isfinite(got).all()
