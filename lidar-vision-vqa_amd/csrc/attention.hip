@@ -37,8 +37,9 @@ struct AttnArgs {
     int nsplit;       // KV splits (flash-decoding style) for few-queries x many-keys shapes
     int nqt;          // query tiles (of 64*QT queries)
     float *part;      // [B*H][nsplit][Nq][dh + 2] fp32 partial (unnormalised O | m | l) when nsplit > 1
-    // tiled key stream (k_attn32 only; bev_tiles.hip): tile t of batch b starts at row tile_src[b * ntiles + t] of k / v when that is
-    // >= 0 (live rows, shared by all batches: k_bs / v_bs are not applied) and at row ~tile_src of k_tab / v_tab otherwise
+    // tiled key stream (k_attn32 only; bev_tiles.hip): the 8 rows of piece p (0..7) of tile t of batch b start at row
+    // tile_src[(b * ntiles + t) * 8 + p] of k / v when that is >= 0 (live rows, shared by all batches: k_bs / v_bs are not applied)
+    // and at row ~tile_src of k_tab / v_tab otherwise
     const int32_t *tile_src;
     const uint16_t *k_tab, *v_tab;
 };
@@ -612,33 +613,38 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
         doff[j] = (uint32_t)(row * (isv ? a.ldv : a.ldk) + ((pch ^ f) << 3));
     }
     const int64_t kstep = (int64_t)KVB * a.ldk, vstep = (int64_t)KVB * a.ldv;
-    // tiled stream: lane l keeps the source row of tile tsv_base + l; a tile's row is a v_readlane away (no memory operation in
-    // the per-tile path: a scalar load there would sit in lgkmcnt beside the counted LDS waits), refreshed every 64 tiles
-    const int32_t *tsrc_b = tiled ? a.tile_src + (int64_t)wave_b * (a.Nkv / KVB) : nullptr;
-    int tsv_base = 0, tsv = 0;
-    auto tsv_load = [&](int tb) __attribute__((always_inline)) {
-        tsv_base = tb;
-        const int n_t = a.Nkv / KVB, tt = tb + lane;
-        tsv = tsrc_b[tt < n_t ? tt : n_t - 1];
+    // tiled stream: lane l keeps the source row of piece (l & 7) of tile tsv_base + (l >> 3); a piece's row is a v_readlane away (no
+    // memory operation in the per-tile path: a scalar load there would sit in lgkmcnt beside the counted LDS waits).  The next
+    // 8 tiles' sources are requested 8 tiles ahead (tsv_nx).
+    const int32_t *tsrc_b = tiled ? a.tile_src + (int64_t)wave_b * (a.Nkv / KVB) * 8 : nullptr;
+    int tsv_base = 0, tsv = 0, tsv_nx = 0;
+    auto tsv_fetch = [&](int tb) __attribute__((always_inline)) -> int {
+        const int n_e = (a.Nkv / KVB) * 8, e = tb * 8 + lane;
+        return tsrc_b[e < n_e ? e : n_e - 1];
     };
+    uint32_t dofft[NPC];                                       // tiled form of doff: row r8 of the piece (the piece's first row is the source row)
+#pragma unroll
+    for (int j = 0; j < NPC; ++j) {
+        const int pc = wid + NW * j, isv = (pc >> 3) & 1, piece = pc & 7, row = piece * 8 + r8;
+        const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
+        dofft[j] = (uint32_t)(r8 * (isv ? a.ldv : a.ldk) + ((pch ^ f) << 3));
+    }
     auto dma = [&](int t, int slot) __attribute__((always_inline)) {
-        const uint16_t *kt, *vt;                                               // wave-uniform
-        if (tiled) {
-            if (t - tsv_base >= 64) tsv_load(t);
-            const int src = __builtin_amdgcn_readlane(tsv, t - tsv_base);
-            const int64_t row = src >= 0 ? src : ~src;
-            kt = (src >= 0 ? kbase : ktab) + row * a.ldk;
-            vt = (src >= 0 ? vbase : vtab) + row * a.ldv;
-        } else {
-            kt = kbase + t * kstep;
-            vt = vbase + t * vstep;
-        }
+        if (tiled && t - tsv_base >= 8) { tsv = tsv_nx; tsv_base += 8; tsv_nx = tsv_fetch(tsv_base + 8); }
+        const uint16_t *kt = kbase + t * kstep, *vt = vbase + t * vstep;       // wave-uniform (untiled form)
 #pragma unroll
         for (int j = 0; j < NPC; ++j) {
             const int pc = wid + NW * j;                       // wave-uniform
             if (pc < 16) {
                 const int isv = pc >> 3, piece = pc & 7;
-                const uint16_t *src = (isv ? vt : kt) + doff[j];
+                const uint16_t *src;
+                if (tiled) {
+                    const int sr = __builtin_amdgcn_readlane(tsv, ((t - tsv_base) << 3) | piece);
+                    const int64_t row = sr >= 0 ? sr : ~sr;
+                    src = (isv ? (sr >= 0 ? vbase : vtab) + row * a.ldv : (sr >= 0 ? kbase : ktab) + row * a.ldk) + dofft[j];
+                } else {
+                    src = (isv ? vt : kt) + doff[j];
+                }
                 uint16_t *dst = smem + slot * TILE_E + isv * (KVB * KROW) + piece * 512;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                  (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
@@ -796,7 +802,7 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
     auto stream = [&](auto slow_tag) __attribute__((always_inline)) {
         constexpr bool SLOW = decltype(slow_tag)::value;
         slot = 0;
-        if (tiled) tsv_load(t0);
+        if (tiled) { tsv_base = t0; tsv = tsv_fetch(t0); tsv_nx = tsv_fetch(t0 + 8); }
         if (t0 < t1) dma(t0, 0);
         if (t0 + 1 < t1) dma(t0 + 1, 1);
         if (t0 + 1 < t1) {                                     // tile t0 landed, tile t0+1 may still fly
@@ -1140,8 +1146,8 @@ extern "C" size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, 
 
 extern "C" int lvq_attention_stream_ok(int nq, int nkv, int dh) { return plan_k32_waves(nq, nkv, dh, false) != 0; }
 
-// VATLiDAR's cross-attention over the TILED key stream of bev_tiles.hip: batch b attends to n_tiles x 64 keys, tile t read from row
-// tile_src[b * n_tiles + t] of the live K|V rows (>= 0) or from row ~tile_src of the per-model table.  Long-stream kernel only
+// VATLiDAR's cross-attention over the TILED key stream of bev_tiles.hip: batch b attends to n_tiles x 64 keys; the 8 rows of piece p
+// of tile t come from row piece_src[(b * n_tiles + t) * 8 + p] of the live K|V rows (>= 0) or from row ~piece_src of the per-model table.  Long-stream kernel only
 // (head_dim 64, n_tiles * 64 >= 4096, lvq_attention_stream_ok(nq, 64 n_tiles, 64)); q plain or hi + lo, K / V plain.
 extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_live, const lvq_bf16 *v_live,
                                         const lvq_bf16 *k_table, const lvq_bf16 *v_table, const int32_t *tile_src, int batch, int n_heads,

@@ -3,13 +3,15 @@
 // A BEV cell whose 3x3 neighbourhood holds no pillar yields a token that depends on the weights only:
 //     x[cell] = LayerNorm(proj(GELU(b_dw))) + PE[cell]        (refine conv -> 1x1 conv -> LayerNorm -> positional table)
 // and so do its K|V rows.  At nuScenes densities that is ~3/4 of the 512 x 512 cells.  The stream is therefore cut into
-// 8 x 8-cell TILES (64 keys = one attention K/V tile; key order is free under softmax, so keys run tile-major):
-//   * a tile whose 10 x 10 halo holds no pillar is CLEAN: its K|V rows come from a per-model table that is computed once per
+// 8 x 8-cell TILES (64 keys = one attention K/V tile; key order is free under softmax, so keys run tile-major) of eight
+// 2 x 4-cell PIECES (8 keys = 8 rows = one 1-KiB LDS-DMA piece of the attention kernel's K or V tile):
+//   * a piece whose 4 x 6 halo holds no pillar is CLEAN: its K|V rows come from a per-model table that is computed once per
 //     weights version by the very same kernels on an empty scene (bit-identical rows by construction);
-//   * every other tile is LIVE: its tokens are computed here, its K|V rows by the GEMM over the compacted live rows, and the
-//     attention kernel reads each tile through one row offset (lvq_attention_bf16_tiled).
-// This file holds (1) the tile bookkeeping: flags, compaction in (tile, scene) order so that the scenes sharing a positional
-// table tile run back to back, the per-(scene, tile) source offsets; and (2) the fused token kernel: pillar gather + depthwise
+//   * every other piece is LIVE: its tokens are computed here, its K|V rows by the GEMM over the compacted live rows, and the
+//     attention kernel reads each piece of a tile through its own row offset (lvq_attention_bf16_tiled).
+//   Live fraction of the bench scenes by granularity: 8 x 8 tiles 56.4 %, 4 x 4 43.5 %, 2 x 4 pieces 38.8 %, single cells 27.6 %.
+// This file holds (1) the bookkeeping: live flags, compaction in (tile, scene, piece) order so that the scenes sharing a
+// positional table tile run back to back, the per-(scene, tile, piece) source offsets; and (2) the fused token kernel: pillar gather + depthwise
 // 3x3 + GELU (same tap order and fmaf chain as k_dwconv3x3_gelu) -> 1x1 conv on MFMA with W held in REGISTERS (column-
 // stationary: wave w owns N/8 output columns, so W is never re-read and needs no LDS) -> LayerNorm (per-wave (mean, M2)
 // partials merged with Chan's formula) -> + positional table -> bf16 rows, without any intermediate in HBM.
@@ -28,82 +30,110 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     return *reinterpret_cast<uint32_t *>(&p);
 }
 
-constexpr int TS = 8, TCELLS = 64, HALO = 10, NHALO = 100;
+constexpr int TS = 8, TCELLS = 64;                 // tile side (cells), keys per tile
+constexpr int NPIECE = 8, PCELLS = 8;              // pieces per tile, cells per piece (2 rows x 4 columns)
+constexpr int PH = 4, PW = 6, PHALO = PH * PW;     // a piece's halo (2 + 2 rows, 4 + 2 columns)
+constexpr int NSLOT = NPIECE * PHALO;              // halo slots of one 8-piece work item (192)
+constexpr int CNT_BLOCK = 1024;                    // pieces per counting block
 
-// ---- tile flags: one thread per (scene, tile); live iff any pillar in the 10 x 10 halo (or `force`) ----
-__global__ void __launch_bounds__(256) k_tile_flags(const int32_t *__restrict__ idx, int S, int H, int W, int force, uint8_t *__restrict__ flags) {
-    const int tw = W / TS, th = H / TS, nt = tw * th;
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= (int64_t)S * nt) {
-        if (g < (int64_t)S * nt + 16 * 1024 + 64) flags[g] = 0;                // padding read by k_tile_compact's 16-byte loads
-        return;
-    }
-    const int s = (int)(g / nt), t = (int)(g % nt);
-    bool live = force != 0;
-    if (!live) {
-        const int y0 = (t / tw) * TS - 1, x0 = (t % tw) * TS - 1;
-        const int32_t *plane = idx + (int64_t)s * H * W;
-        for (int r = 0; r < HALO && !live; ++r) {
-            const int gy = y0 + r;
-            if (gy < 0 || gy >= H) continue;
-            for (int c = 0; c < HALO; ++c) {
-                const int gx = x0 + c;
-                if (gx >= 0 && gx < W && plane[(int64_t)gy * W + gx] >= 0) { live = true; break; }
-            }
-        }
-    }
-    flags[(int64_t)t * S + s] = live ? 1 : 0;            // (tile, scene) order
+// origin (y, x) of piece p of tile t: row pair p >> 1, column half p & 1
+__device__ __forceinline__ void piece_origin(int t, int p, int tw, int &y0, int &x0) {
+    y0 = (t / tw) * TS + (p >> 1) * 2;
+    x0 = (t % tw) * TS + (p & 1) * 4;
 }
 
-// ---- compaction: exclusive scan of the flags in (tile, scene) order (single workgroup; <= 4 M flags) ----
-//   live_list[k]           = t * S + s of the k-th live tile
-//   tile_src[s * nt + t]   = 64 * k (first row of the tile in the live buffer)  or  ~(64 * t) (row of the table) when clean
-//   counts[0] = number of live tiles, counts[1] = live rows (64 x)
-__global__ void __launch_bounds__(1024) k_tile_compact(const uint8_t *__restrict__ flags, int S, int nt, int32_t *__restrict__ live_list,
-                                                      int32_t *__restrict__ tile_src, int32_t *__restrict__ counts) {
-    __shared__ int wave_tot[16];
-    const int64_t total = (int64_t)S * nt;
-    const int per = (int)(((total + 1023) / 1024 + 15) / 16 * 16);      // flags per thread, whole 16-byte words (the buffer is padded)
-    const int64_t b0 = (int64_t)threadIdx.x * per;
-    int c = 0;
-    for (int j = 0; j < per; j += 16) {
-        if (b0 + j >= total) break;
-        const uint4 v = *reinterpret_cast<const uint4 *>(flags + b0 + j);       // bytes past `total` are zero (k_tile_flags pads)
-        c += __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w);            // flags are 0 / 1
-    }
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    int incl = c;
+// live flag of flat index i = (t * S + s) * 8 + p : any pillar in the 4 x 6 halo (or `force`)
+__device__ __forceinline__ bool piece_live(const int32_t *__restrict__ idx, int64_t i, int S, int H, int W, int force) {
+    if (force) return true;
+    const int tw = W / TS;
+    const int p = (int)(i & 7);
+    const int64_t ts = i >> 3;
+    const int t = (int)(ts / S), s = (int)(ts - (int64_t)t * S);
+    int y0, x0;
+    piece_origin(t, p, tw, y0, x0);
+    const int32_t *plane = idx + (int64_t)s * H * W;
+    bool live = false;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o);
-        if (lane >= o) incl += t;
-    }
-    if (lane == 63) wave_tot[wid] = incl;
-    __syncthreads();
-    int base = 0, tot = 0;
-    for (int w = 0; w < 16; ++w) {
-        const int t = wave_tot[w];
-        if (w < wid) base += t;
-        tot += t;
-    }
-    int k = base + incl - c;
-    for (int j = 0; j < per; ++j) {
-        const int64_t i = b0 + j;
-        if (i >= total) break;
-        const int t = (int)(i / S), s = (int)(i % S);
-        if (flags[i]) {
-            live_list[k] = (int32_t)i;
-            tile_src[(int64_t)s * nt + t] = k * TCELLS;
-            ++k;
-        } else {
-            tile_src[(int64_t)s * nt + t] = ~(t * TCELLS);
+    for (int r = 0; r < PH; ++r) {
+        const int gy = y0 - 1 + r;
+        if (gy < 0 || gy >= H) continue;
+#pragma unroll
+        for (int c = 0; c < PW; ++c) {
+            const int gx = x0 - 1 + c;
+            if (gx >= 0 && gx < W) live = live || plane[(int64_t)gy * W + gx] >= 0;
         }
     }
-    if (threadIdx.x == 0) { counts[0] = tot; counts[1] = tot * TCELLS; }
+    return live;
+}
+
+// ---- pass 1: live pieces per block of CNT_BLOCK flat indices ----
+__global__ void __launch_bounds__(256) k_piece_count(const int32_t *__restrict__ idx, int S, int H, int W, int force, int64_t total,
+                                                     int32_t *__restrict__ block_cnt) {
+    __shared__ int wsum[4];
+    int c = 0;
+#pragma unroll
+    for (int u = 0; u < CNT_BLOCK / 256; ++u) {
+        const int64_t i = (int64_t)blockIdx.x * CNT_BLOCK + u * 256 + threadIdx.x;
+        if (i < total) c += piece_live(idx, i, S, H, W, force) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ---- pass 2: every block re-sums the block counts in front of it (<= a few thousand L2-resident values), recomputes its flags and
+// writes, in (tile, scene, piece) order,
+//   live_list[k]                    = flat index (t * S + s) * 8 + p of the k-th live piece
+//   piece_src[(s * nt + t) * 8 + p] = 8 k (first row of the piece among the live rows) or ~(64 t + 8 p) (its row in the table)
+//   counts[0] = live pieces, counts[1] = live rows (8 x), by the last block
+__global__ void __launch_bounds__(256) k_piece_compact(const int32_t *__restrict__ idx, int S, int H, int W, int force, int64_t total,
+                                                       const int32_t *__restrict__ block_cnt, int nblocks, int32_t *__restrict__ live_list,
+                                                       int32_t *__restrict__ piece_src, int32_t *__restrict__ counts) {
+    __shared__ int wsum[4];
+    __shared__ int l_base;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int c = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) c += block_cnt[b];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) wsum[wid] = c;
+    __syncthreads();
+    if (tid == 0) l_base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    int base = l_base;
+    const int nt = (H / TS) * (W / TS);
+    for (int u = 0; u < CNT_BLOCK / 256; ++u) {
+        const int64_t i = (int64_t)blockIdx.x * CNT_BLOCK + u * 256 + tid;
+        const bool live = i < total && piece_live(idx, i, S, H, W, force);
+        const unsigned long long m = __ballot(live);
+        __syncthreads();
+        if (lane == 0) wsum[wid] = __popcll(m);
+        __syncthreads();
+        int wb = 0, tot = 0;
+        for (int q = 0; q < 4; ++q) { if (q < wid) wb += wsum[q]; tot += wsum[q]; }
+        if (i < total) {
+            const int p = (int)(i & 7);
+            const int64_t ts = i >> 3;
+            const int t = (int)(ts / S), sc = (int)(ts - (int64_t)t * S);
+            const int64_t o = ((int64_t)sc * nt + t) * NPIECE + p;
+            if (live) {
+                const int k = base + wb + __popcll(m & ((1ull << lane) - 1ull));
+                live_list[k] = (int32_t)i;
+                piece_src[o] = k * PCELLS;
+            } else {
+                piece_src[o] = ~(t * TCELLS + p * PCELLS);
+            }
+        }
+        base += tot;
+    }
+    if ((int)blockIdx.x == nblocks - 1 && tid == 0) { counts[0] = base; counts[1] = base * PCELLS; }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// fused token kernel.  512 threads = 8 waves; persistent over the live list.
+// fused token kernel.  512 threads = 8 waves; persistent over the live list.  A work item ("group") = 8 consecutive live pieces =
+// 64 rows = four 16-row MFMA groups; its pieces may belong to different tiles / scenes, each brings its own 4 x 6 halo.
 //   J   = 16-column MFMA tiles per wave (N = 128 J: 768 -> 6, 1024 -> 8, 512 -> 4, 256 -> 2; even, so a lane's 8 J output bytes stay 16-byte aligned)
 //   X3  = operands hi + lo (t and W), products hi*hi + hi*lo + lo*hi
 //   OLO = also write the lo half of x (bf16x3 consumers); the mixed mode keeps x plain
@@ -111,20 +141,20 @@ __global__ void __launch_bounds__(1024) k_tile_compact(const uint8_t *__restrict
 // W row permutation n = 16 J w + 4 J (m >> 2) + 4 j + (m & 3) for A row m of column tile j, lane (cell = l & 15, g4 = l >> 4)
 // owns the 4 J CONSECUTIVE columns 16 J w + 4 J g4 .. of its cell: positional-table reads are J float4 and the output leaves
 // as J/2 (or so) 16-byte stores, 4 lanes covering 32 J contiguous bytes of a row.
-// Per tile: [B1: t tile ready] DMA of the next tile's pillar rows, pass 1 (MFMA -> per-wave (mean, M2)), [B2] conv of the next
-// tile (LDS only), pass 2 (MFMA again -> normalise -> + table -> store): two barriers, no HBM intermediate.
+// Per group: [B1: conv tokens ready] DMA of the next group's pillar rows, pass 1 (MFMA -> per-wave (mean, M2)), [B2] conv of the
+// next group (LDS only), pass 2 (MFMA again -> normalise -> + table -> store): two barriers, no HBM intermediate.
 // ---------------------------------------------------------------------------------------------------------
 struct TokArgs {
     const float *feat;            // [M, 64] pillar features
     const int32_t *idx;           // [S, H, W] pillar row or -1
-    const int32_t *live_list;     // (tile, scene) codes
-    const int32_t *counts;        // counts[0] = live tiles
+    const int32_t *live_list;     // flat piece indices (t * S + s) * 8 + p
+    const int32_t *counts;        // counts[0] = live pieces
     const float *w9, *b9;         // depthwise conv [64, 9], [64]
     const uint16_t *wh, *wl;      // 1x1 conv [N, 64] bf16 hi / lo
     const float *bias, *gamma, *beta, *pe;     // [N], [N], [N], positional table [H*W (tile-major), N]
     float eps;
     int S, H, W;
-    uint16_t *xh, *xl;            // [cap * 64, N]
+    uint16_t *xh, *xl;            // [cap rows, N]: row 8 k + (2 x 4 cell index) of live piece k
 };
 
 template <int J, bool X3, bool OLO>
@@ -134,15 +164,16 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
     // LDS map
     uint16_t *t_hi = reinterpret_cast<uint16_t *>(smem);                      // [2][64][64] bf16, 128-byte rows, chunk-swizzled
     uint16_t *t_lo = t_hi + 2 * TCELLS * C;                                   // [2][64][64]
-    float *halo = reinterpret_cast<float *>(t_lo + 2 * TCELLS * C);           // [100][64] fp32 pillar rows of the halo (live slots only)
-    int32_t *idxh = reinterpret_cast<int32_t *>(halo + NHALO * C);            // [2][128]
-    float *part = reinterpret_cast<float *>(idxh + 2 * 128);                  // [2][8 waves][64 cells][2]
+    float *halo = reinterpret_cast<float *>(t_lo + 2 * TCELLS * C);           // [192][64] fp32 pillar rows of the 8 halos (live slots only)
+    int32_t *idxh = reinterpret_cast<int32_t *>(halo + NSLOT * C);            // [2][256]: 192 halo indices + 8 piece codes at [200..207]
+    float *part = reinterpret_cast<float *>(idxh + 2 * 256);                  // [2][8 waves][64 cells][2]
     float *pbias = part + 2 * NWV * TCELLS * 2, *pgam = pbias + N, *pbet = pgam + N;
     float *w9s = pbet + N;                                                    // [9][64]
     float *b9s = w9s + 9 * C;                                                 // [64]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
-    const int tw = a.W / TS, nt = tw * (a.H / TS);
-    const int n_live = a.counts[0];
+    const int tw = a.W / TS;
+    const int n_live = a.counts[0];                             // live pieces
+    const int64_t n_groups = ((int64_t)n_live + NPIECE - 1) / NPIECE;
 
     for (int e = tid; e < N; e += 512) { pbias[e] = a.bias ? a.bias[e] : 0.f; pgam[e] = a.gamma[e]; pbet[e] = a.beta ? a.beta[e] : 0.f; }
     for (int e = tid; e < 9 * C; e += 512) w9s[e] = a.w9[(e % C) * 9 + e / C];
@@ -162,38 +193,46 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
     }
     const int col0 = 16 * J * wid + 4 * J * g4;                  // this lane's first column (4 J consecutive ones)
 
-    // work order: every workgroup takes one CONTIGUOUS run of the (tile, scene)-ordered list, so the scenes that share a positional
-    // table tile (196 KB of fp32) are served back to back by the same workgroup: the first read of the tile comes from HBM, the
-    // repeats hit the XCD's L2 (with the runs dealt round-robin all sharers missed at once and every group of 16 cells paid an HBM
-    // round trip: 21 us per tile)
-    const int64_t chunk = ((int64_t)n_live + gridDim.x - 1) / gridDim.x;
-    const int64_t k_begin = (int64_t)blockIdx.x * chunk, k_end = k_begin + chunk < n_live ? k_begin + chunk : n_live;
-    auto tile_at = [&](int64_t it, int &s, int &t, int64_t &k) -> bool {      // it-th tile of this workgroup
-        k = k_begin + it;
-        if (k >= k_end) return false;
+    // work order: every workgroup takes one CONTIGUOUS run of the (tile, scene, piece)-ordered list, so the scenes that share a
+    // positional table tile are served back to back by the same workgroup (first read from HBM, repeats from the XCD's L2)
+    const int64_t chunk = (n_groups + gridDim.x - 1) / gridDim.x;
+    const int64_t g_begin = (int64_t)blockIdx.x * chunk, g_end = g_begin + chunk < n_groups ? g_begin + chunk : n_groups;
+    // halo index of slot tid (< 192) of group g: piece j = tid / 24 (code = live_list[8 g + j]), halo cell tid % 24; threads with
+    // tid % 24 == 0 also return the piece code (-1 past the end of the list)
+    auto load_idx = [&](int64_t g, int &code_out) -> int {
+        code_out = -1;
+        if (tid >= NSLOT) return -1;
+        const int j = tid / PHALO, hc = tid - j * PHALO;
+        const int64_t k = g * NPIECE + j;
+        if (k >= n_live) return -1;
         const int code = a.live_list[k];
-        t = code / a.S; s = code - t * a.S;
-        return true;
+        code_out = code;
+        const int p = code & 7, ts = code >> 3, t = ts / a.S, sc = ts - t * a.S;
+        int y0, x0;
+        piece_origin(t, p, tw, y0, x0);
+        const int gy = y0 - 1 + hc / PW, gx = x0 - 1 + hc % PW;
+        return (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? a.idx[((int64_t)sc * a.H + gy) * a.W + gx] : -1;
     };
-    // halo indices of a tile -> idxh[buf] (threads 0..99)
-    auto load_idx = [&](int s, int t) -> int {
-        if (tid >= NHALO || s < 0) return -1;
-        const int gy = (t / tw) * TS - 1 + tid / HALO, gx = (t % tw) * TS - 1 + tid % HALO;
-        return (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? a.idx[((int64_t)s * a.H + gy) * a.W + gx] : -1;
+    auto store_idx = [&](int32_t *ih, int v, int code) {
+        if (tid < NSLOT) {
+            ih[tid] = v;
+            if (tid % PHALO == 0) ih[200 + tid / PHALO] = code;
+        }
     };
     // LDS-DMA of the live halo rows (256 B each): 4 slots per wave instruction, 16 lanes per slot; empty slots are skipped
     auto dma_halo = [&](const int32_t *ih) {
-        for (int p = wid; p < NHALO / 4; p += NWV) {
-            const int slot = p * 4 + (lane >> 4);
+        for (int q = wid; q < NSLOT / 4; q += NWV) {
+            const int slot = q * 4 + (lane >> 4);
             const int row = ih[slot];
             if (row >= 0)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.feat + (int64_t)row * C + 4 * l15),
-                                                 (__attribute__((address_space(3))) void *)(halo + p * 4 * C), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(halo + q * 4 * C), 16, 0, 0);
         }
     };
-    // depthwise 3x3 + GELU of one tile from the staged halo rows: thread (cell = tid >> 3, channels 8 (tid & 7) .. +7)
+    // depthwise 3x3 + GELU of one group from the staged halo rows: thread (cell = tid >> 3, channels 8 (tid & 7) .. +7); cell =
+    // 8 j + 4 r + c of piece j (2 x 4), whose halo is 4 x 6
     auto conv_tile = [&](const int32_t *ih, int buf) {
-        const int cell = tid >> 3, cg = (tid & 7) * 8, cy = cell >> 3, cx = cell & 7;
+        const int cell = tid >> 3, cg = (tid & 7) * 8, hb = (cell >> 3) * PHALO, cy = (cell >> 2) & 1, cx = cell & 3;
         float acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = b9s[cg + c];
@@ -201,7 +240,7 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
         for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const int slot = (cy + rr) * HALO + cx + k;
+                const int slot = hb + (cy + rr) * PW + cx + k;
                 if (ih[slot] >= 0) {                              // a zero tap leaves the accumulator unchanged exactly
                     const f32x4 v0 = *reinterpret_cast<const f32x4 *>(halo + slot * C + cg), v1 = *reinterpret_cast<const f32x4 *>(halo + slot * C + cg + 4);
                     const f32x4 k0 = *reinterpret_cast<const f32x4 *>(w9s + (rr * 3 + k) * C + cg), k1 = *reinterpret_cast<const f32x4 *>(w9s + (rr * 3 + k) * C + cg + 4);
@@ -271,17 +310,16 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
         m2 = q;
     };
 
-    // ---- prologue: tile 0 staged synchronously, indices of tile 1 in LDS ----
-    int s_cur, t_cur, s_nx, t_nx, s_n2, t_n2;
-    int64_t k_cur, k_nx, k_n2;
-    bool has_cur = tile_at(0, s_cur, t_cur, k_cur);
-    bool has_nx = tile_at(1, s_nx, t_nx, k_nx);
-    if (tid < 128) { idxh[tid] = -1; idxh[128 + tid] = -1; }
+    // ---- prologue: group 0 staged synchronously, indices of group 1 in LDS ----
+    if (tid < 256) { idxh[tid] = -1; idxh[256 + tid] = -1; }
     __syncthreads();
-    if (!has_cur) return;
+    if (g_begin >= g_end) return;
     {
-        const int i0 = load_idx(s_cur, t_cur), i1 = has_nx ? load_idx(s_nx, t_nx) : -1;
-        if (tid < NHALO) { idxh[tid] = i0; idxh[128 + tid] = i1; }
+        int c0, c1;
+        const int i0 = load_idx(g_begin, c0);
+        const int i1 = g_begin + 1 < g_end ? load_idx(g_begin + 1, c1) : (c1 = -1, -1);
+        store_idx(idxh, i0, c0);
+        store_idx(idxh + 256, i1, c1);
     }
     __syncthreads();
     dma_halo(idxh);
@@ -289,12 +327,19 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
     __syncthreads();
     conv_tile(idxh, 0);
     int buf = 0;
-    for (int64_t it = 0; has_cur; ++it) {
+    for (int64_t g = g_begin; g < g_end; ++g) {
+        const int64_t it = g - g_begin;
         __syncthreads();                                          // B1: t[buf] complete, halo buffer free, part[buf] free
-        const int32_t *ih_nx = idxh + ((it + 1) & 1) * 128;
+        const int32_t *ih_cur = idxh + (it & 1) * 256, *ih_nx = idxh + ((it + 1) & 1) * 256;
+        const bool has_nx = g + 1 < g_end, has_n2 = g + 2 < g_end;
         if (has_nx) dma_halo(ih_nx);
-        const bool has_n2 = tile_at(it + 2, s_n2, t_n2, k_n2);
-        const int i2 = has_n2 ? load_idx(s_n2, t_n2) : -1;
+        // piece codes of THIS group for pass 2 (its slot of idxh is overwritten before B2): lane's cell of group gq belongs to piece
+        // 2 gq + (l15 >> 3)
+        int code_cur[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) code_cur[gq] = ih_cur[200 + 2 * gq + (l15 >> 3)];
+        int c2 = -1;
+        const int i2 = has_n2 ? load_idx(g + 2, c2) : -1;
         // ---- pass 1: per-wave (mean, M2) of every cell over this wave's 16 J columns ----
         float *pw = part + ((buf * NWV + wid) * TCELLS) * 2;
 #pragma unroll 1
@@ -317,18 +362,21 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
             const float mw = ma + 0.5f * dlt, m2 = qa + qb + dlt * dlt * (0.5f * (float)(16 * JH));
             if (g4 == 0) { pw[(gq * 16 + l15) * 2] = mw; pw[(gq * 16 + l15) * 2 + 1] = m2; }
         }
-        if (tid < NHALO) idxh[(it & 1) * 128 + tid] = i2;         // indices of tile it+2 replace those of tile it (its conv is done)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's halo DMA (tile it+1) has landed
-        __syncthreads();                                          // B2: partials complete; every wave's DMA landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's halo DMA (group it+1) has landed
+        __syncthreads();                                          // B2: partials complete; every wave's DMA landed; codes of group it read
+        store_idx(idxh + (it & 1) * 256, i2, c2);                 // indices of group it+2 replace those of group it (visible after B1)
         if (has_nx) conv_tile(ih_nx, buf ^ 1);
         // ---- pass 2: merge the 8 partials (Chan), recompute, normalise, + table, store ----
-        if (s_cur >= 0) {
+        {
             const float *pr = part + (buf * NWV * TCELLS) * 2;
-            const int64_t prow0 = (int64_t)t_cur * TCELLS, orow0 = k_cur * TCELLS;
+            const int64_t orow0 = g * TCELLS;
 #pragma unroll 1
             for (int gq = 0; gq < 4; ++gq) {
                 const int cell = gq * 16 + l15;
-                const float *pep = a.pe + (prow0 + cell) * N + col0;
+                const int code = gq == 0 ? code_cur[0] : gq == 1 ? code_cur[1] : gq == 2 ? code_cur[2] : code_cur[3];
+                const bool valid = code >= 0;                       // false past the end of the live list (last group only): no store
+                const int64_t prow = valid ? (int64_t)((code >> 3) / a.S) * TCELLS + (code & 7) * PCELLS + (cell & 7) : 0;
+                const float *pep = a.pe + prow * N + col0;
                 f32x4 pe0[JH], pe1[JH];                            // requested up front (HBM), consumed per half
 #pragma unroll
                 for (int jj = 0; jj < JH; ++jj) pe0[jj] = *reinterpret_cast<const f32x4 *>(pep + 4 * jj);
@@ -370,19 +418,18 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
                     }
                     // 4 J bytes per half and lane: J/2 8-byte pieces (16-byte stores where a pair is whole)
                     static_assert(J % 2 == 0, "even J");
+                    if (valid) {
 #pragma unroll
-                    for (int q = 0; q < 2 * JH; q += 2) {
-                        *reinterpret_cast<uint2 *>(dst + 2 * (2 * HF * JH + q)) = make_uint2(oh[q], oh[q + 1]);
-                        if (OLO) *reinterpret_cast<uint2 *>(dl + 2 * (2 * HF * JH + q)) = make_uint2(ol[q], ol[q + 1]);
+                        for (int q = 0; q < 2 * JH; q += 2) {
+                            *reinterpret_cast<uint2 *>(dst + 2 * (2 * HF * JH + q)) = make_uint2(oh[q], oh[q + 1]);
+                            if (OLO) *reinterpret_cast<uint2 *>(dl + 2 * (2 * HF * JH + q)) = make_uint2(ol[q], ol[q + 1]);
+                        }
                     }
                 };
                 half_out(std::integral_constant<int, 0>{}, pe0);
                 half_out(std::integral_constant<int, 1>{}, pe1);
             }
         }
-        // rotate
-        has_cur = has_nx; s_cur = s_nx; t_cur = t_nx; k_cur = k_nx;
-        has_nx = has_n2; s_nx = s_n2; t_nx = t_n2; k_nx = k_n2;
         buf ^= 1;
     }
 }
@@ -394,25 +441,28 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
 // =================================================================================================
 extern "C" size_t lvq_bev_tiles_workspace_bytes(int batch, int ny, int nx) {
     if (batch <= 0 || ny <= 0 || nx <= 0) return 0;
-    return lvq_align((size_t)batch * (ny / 8) * (nx / 8) + 16 * 1024 + 64) + 512;          // one flag byte per (tile, scene) + zero padding
+    const int64_t total = (int64_t)batch * (ny / 8) * (nx / 8) * bt::NPIECE;
+    return lvq_align((size_t)lvq_cdiv(total, bt::CNT_BLOCK) * sizeof(int32_t)) + 512;      // one live count per counting block
 }
 
-extern "C" int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, int force_all, int32_t *live_list, int32_t *tile_src,
+extern "C" int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, int force_all, int32_t *live_list, int32_t *piece_src,
                              int32_t *counts, void *ws, size_t ws_bytes, lvq_stream_t stream) {
-    if (batch <= 0 || ny <= 0 || nx <= 0 || !live_list || !tile_src || !counts || (!idx_map && !force_all)) return LVQ_EINVAL;
+    if (batch <= 0 || ny <= 0 || nx <= 0 || !live_list || !piece_src || !counts || (!idx_map && !force_all)) return LVQ_EINVAL;
     if ((ny % 8) || (nx % 8)) return LVQ_EUNSUPPORTED;
-    const int64_t nt = (int64_t)(ny / 8) * (nx / 8), total = nt * batch;
-    if (total > (1 << 22)) return LVQ_EUNSUPPORTED;
+    const int64_t total = (int64_t)batch * (ny / 8) * (nx / 8) * bt::NPIECE;
+    if (total > (1 << 27)) return LVQ_EUNSUPPORTED;                  // flat piece indices and 8 x row offsets stay in int32
     if (!ws || ws_bytes < lvq_bev_tiles_workspace_bytes(batch, ny, nx)) return LVQ_EWORKSPACE;
-    uint8_t *flags = (uint8_t *)ws;
+    int32_t *block_cnt = (int32_t *)ws;
+    const int nb = (int)lvq_cdiv(total, bt::CNT_BLOCK);
     hipStream_t st = lvq_s(stream);
-    hipLaunchKernelGGL(bt::k_tile_flags, dim3((unsigned)lvq_cdiv(total + 16 * 1024 + 64, 256)), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, flags);
-    hipLaunchKernelGGL(bt::k_tile_compact, dim3(1), dim3(1024), 0, st, flags, batch, (int)nt, live_list, tile_src, counts);
+    hipLaunchKernelGGL(bt::k_piece_count, dim3(nb), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, total, block_cnt);
+    hipLaunchKernelGGL(bt::k_piece_compact, dim3(nb), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, total, (const int32_t *)block_cnt, nb,
+                       live_list, piece_src, counts);
     return lvq_launch_status();
 }
 
 template <int J> static int launch_tile_tokens(const bt::TokArgs &a, bool x3, bool olo, int64_t cap_tiles, hipStream_t st) {
-    const size_t lds = (size_t)2 * 2 * bt::TCELLS * 64 * 2 + (size_t)bt::NHALO * 64 * 4 + 2 * 128 * 4 + (size_t)2 * 8 * bt::TCELLS * 2 * 4 +
+    const size_t lds = (size_t)2 * 2 * bt::TCELLS * 64 * 2 + (size_t)bt::NSLOT * 64 * 4 + 2 * 256 * 4 + (size_t)2 * 8 * bt::TCELLS * 2 * 4 +
                        (size_t)3 * 128 * J * 4 + 9 * 64 * 4 + 64 * 4;
     static LvqLdsOnce once;
     if (!lvq_ensure_lds(once, {(const void *)bt::k_tile_tokens<J, false, false>, (const void *)bt::k_tile_tokens<J, true, false>,

@@ -303,13 +303,14 @@ class VATLiDAR(_HipModule):
                 and not os.environ.get("LVQ_NO_TILED_STREAM"))
 
     def _pe_tiled(self, H: int, W: int, dev) -> torch.Tensor:
-        """The positional table with its rows in tile-major order (row 64 t + 8 y + x of tile t): a permutation of _pe_table."""
+        """The positional table with its rows in the key order of the tiled stream: tile t (8 x 8 cells) major, then piece p = 2 (y >> 1)
+        + (x >> 2) (2 x 4 cells), then 4 (y & 1) + (x & 3) inside the piece -- a permutation of _pe_table."""
         pe = self._pe_table(H, W, dev)
         hit = self._pe_cache.get(("tiled", H, W, dev))
         if hit is not None and hit[0] is pe:
             return hit[1]
         d = pe.shape[1]
-        pt = pe.view(H // 8, 8, W // 8, 8, d).permute(0, 2, 1, 3, 4).reshape(H * W, d).contiguous()
+        pt = pe.view(H // 8, 4, 2, W // 8, 2, 4, d).permute(0, 3, 1, 4, 2, 5, 6).reshape(H * W, d).contiguous()
         self._pe_cache[("tiled", H, W, dev)] = (pe, pt)
         return pt
 

@@ -228,10 +228,11 @@ _TILE_WS = {}
 
 
 def bev_tiles(idx: Optional[torch.Tensor], batch: int, ny: int, nx: int, device, force_all: bool = False):
-    """Tile bookkeeping -> (live_list [batch*nt] i32, tile_src [batch*nt] i32, counts [2] i32 = live tiles, live rows)."""
+    """Piece bookkeeping of the tiled key stream (8 x 8-cell tiles of eight 2 x 4-cell pieces) ->
+    (live_list [batch*nt*8] i32, piece_src [batch*nt*8] i32, counts [2] i32 = live pieces, live rows)."""
     nt = (ny // 8) * (nx // 8)
-    live = torch.empty((batch * nt,), dtype=torch.int32, device=device)
-    src = torch.empty((batch * nt,), dtype=torch.int32, device=device)
+    live = torch.empty((batch * nt * 8,), dtype=torch.int32, device=device)
+    src = torch.empty((batch * nt * 8,), dtype=torch.int32, device=device)
     counts = torch.empty((2,), dtype=torch.int32, device=device)
     L = F.lib()
     nbytes = int(L.lvq_bev_tiles_workspace_bytes(F.cint(batch), F.cint(ny), F.cint(nx)))

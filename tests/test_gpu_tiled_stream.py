@@ -45,31 +45,34 @@ def test_tile_bookkeeping_vs_numpy(B, H, W, M):
     th, tw = H // 8, W // 8
     nt = th * tw
     pad = np.pad(occ, ((0, 0), (1, 1), (1, 1)))
-    flags = np.zeros((B, nt), bool)
+    flags = np.zeros((B, nt, 8), bool)                                            # piece p of tile t: rows 2 (p >> 1) .. +1, columns 4 (p & 1) .. +3
     for t in range(nt):
-        y0, x0 = (t // tw) * 8, (t % tw) * 8
-        flags[:, t] = pad[:, y0:y0 + 10, x0:x0 + 10].any(axis=(1, 2))
+        for p in range(8):
+            y0, x0 = (t // tw) * 8 + (p >> 1) * 2, (t % tw) * 8 + (p & 1) * 4
+            flags[:, t, p] = pad[:, y0:y0 + 4, x0:x0 + 6].any(axis=(1, 2))     # 4 x 6 halo (padded coordinates)
     live, src, counts = o.bev_tiles(idx, B, H, W, DEV)
     n = int(counts[0])
-    assert n == int(flags.sum()) and int(counts[1]) == 64 * n
-    order = [(t, s) for t in range(nt) for s in range(B) if flags[s, t]]           # (tile, scene) order
-    assert live.cpu().numpy()[:n].tolist() == [t * B + s for t, s in order]
-    want = np.empty((B, nt), np.int64)
-    for k, (t, s) in enumerate(order):
-        want[s, t] = 64 * k
+    assert n == int(flags.sum()) and int(counts[1]) == 8 * n
+    order = [(t, s, p) for t in range(nt) for s in range(B) for p in range(8) if flags[s, t, p]]      # (tile, scene, piece) order
+    assert live.cpu().numpy()[:n].tolist() == [(t * B + s) * 8 + p for t, s, p in order]
+    want = np.empty((B, nt, 8), np.int64)
     for s in range(B):
         for t in range(nt):
-            if not flags[s, t]:
-                want[s, t] = ~(64 * t)
-    assert np.array_equal(src.cpu().numpy().reshape(B, nt), want.astype(np.int32))
+            for p in range(8):
+                want[s, t, p] = ~(64 * t + 8 * p)
+    for k, (t, s, p) in enumerate(order):
+        want[s, t, p] = 8 * k
+    assert np.array_equal(src.cpu().numpy().reshape(B, nt, 8), want.astype(np.int32))
     live2, src2, counts2 = o.bev_tiles(idx, B, H, W, DEV, force_all=True)
-    assert int(counts2[0]) == B * nt and bool((src2 >= 0).all())
+    assert int(counts2[0]) == B * nt * 8 and bool((src2 >= 0).all())
 
 
 def _tile_major(rows_hw: torch.Tensor, H: int, W: int) -> torch.Tensor:
-    """[.., H*W, d] row-major cells -> tile-major rows."""
+    """[.., H*W, d] row-major cells -> the tiled stream's key order: tile (8 x 8) major, piece (2 x 4) next, cell inside the piece last."""
     lead, d = rows_hw.shape[:-2], rows_hw.shape[-1]
-    return rows_hw.view(*lead, H // 8, 8, W // 8, 8, d).transpose(-3, -4).reshape(*lead, H * W, d)
+    n = len(lead)
+    v = rows_hw.view(*lead, H // 8, 4, 2, W // 8, 2, 4, d)                      # (ty, pr, r, tx, pc, c, d)
+    return v.permute(*range(n), n + 0, n + 3, n + 1, n + 4, n + 2, n + 5, n + 6).reshape(*lead, H * W, d)
 
 
 @pytest.mark.parametrize("n,split", [(256, False), (768, False), (768, True), (512, True), (1024, False)])
@@ -99,28 +102,28 @@ def test_tile_tokens_vs_unfused_kernels(n, split):
         x = o.bev_tile_tokens(feat, idx, live, counts, B * nt * 64, B, H, W, w9, b9, o.cast(wp, split), bias, gam, bet, 1e-5, pe_t, out_lo=split)
         got = o.to_f32(x)
         nl = int(counts[0])
-        assert nl == B * nt if force else 0 < nl < B * nt
+        assert nl == B * nt * 8 if force else 0 < nl < B * nt * 8
         codes = live.cpu().numpy()[:nl]
-        for k in (0, 1, nl // 2, nl - 1):
-            tt, s = divmod(int(codes[k]), B)
-            a, b = got[64 * k:64 * k + 64], ref_t[s, 64 * tt:64 * tt + 64]
-            tol = 3e-4 if split else 2.0 ** -7 * float(b.abs().max())
-            assert float((a - b).abs().max()) < tol, (force, k)
-        full = torch.stack([got[64 * k:64 * k + 64] for k in range(nl)])           # every live tile
-        want = torch.stack([ref_t[int(cd) % B, 64 * (int(cd) // B):64 * (int(cd) // B) + 64] for cd in codes])
-        assert float((full - want).abs().max()) < (3e-4 if split else 2.0 ** -7 * float(want.abs().max()))
+        rows = []                                                                 # reference row block of every live piece
+        for cd in codes:
+            p, ts = int(cd) & 7, int(cd) >> 3
+            tt, s = divmod(ts, B)
+            rows.append(ref_t[s, 64 * tt + 8 * p:64 * tt + 8 * p + 8])
+        want = torch.stack(rows).reshape(nl * 8, n)
+        full = got[:nl * 8]
+        assert float((full - want).abs().max()) < (3e-4 if split else 2.0 ** -7 * float(want.abs().max())), force
     # a clean tile equals the all-empty-scene value of that tile (what the per-model table holds), bit for bit
     live_e, src_e, counts_e = o.bev_tiles(torch.full_like(idx[:1], -1), 1, H, W, DEV, force_all=True)
     xe = o.bev_tile_tokens(feat[:1] * 0, torch.full_like(idx[:1], -1), live_e, counts_e, nt * 64, 1, H, W, w9, b9, o.cast(wp, split), bias, gam,
                            bet, 1e-5, pe_t, out_lo=split)
     live_f, src_f, counts_f = o.bev_tiles(idx, B, H, W, DEV, force_all=True)
     xf = o.bev_tile_tokens(feat, idx, live_f, counts_f, B * nt * 64, B, H, W, w9, b9, o.cast(wp, split), bias, gam, bet, 1e-5, pe_t, out_lo=split)
-    srcs = o.bev_tiles(idx, B, H, W, DEV)[1].cpu().numpy().reshape(B, nt)
-    clean = [(s, tt) for s in range(B) for tt in range(nt) if srcs[s, tt] < 0][:50]
+    srcs = o.bev_tiles(idx, B, H, W, DEV)[1].cpu().numpy().reshape(B, nt, 8)
+    clean = [(s, tt, p) for s in range(B) for tt in range(nt) for p in range(8) if srcs[s, tt, p] < 0][:80]
     assert clean
-    for s, tt in clean:
-        k = tt * B + s                                                            # all-live order: entry (tile, scene)
-        assert torch.equal(xf[0][64 * k:64 * k + 64], xe[0][64 * tt:64 * tt + 64])
+    for s, tt, p in clean:
+        k = (tt * B + s) * 8 + p                                                  # all-live order: entry (tile, scene, piece)
+        assert torch.equal(xf[0][8 * k:8 * k + 8], xe[0][64 * tt + 8 * p:64 * tt + 8 * p + 8])
 
 
 def test_gemm_live_rows_device_count():
@@ -151,31 +154,33 @@ def test_gemm_live_rows_device_count():
 
 @pytest.mark.parametrize("B,H,nq,n_tiles,qsplit", [(2, 2, 120, 64, False), (3, 4, 576, 128, True), (1, 12, 576, 256, True)])
 def test_attention_tiled_equals_dense_on_gathered_rows(B, H, nq, n_tiles, qsplit):
-    """Tile t of batch b from the live rows or from the table through tile_src == the dense call on the same rows gathered into
+    """Piece p of tile t of batch b from the live rows or from the table through piece_src == the dense call on the same rows gathered into
     one [B, 64 n_tiles, 2d] buffer: same kernel, same key order -> bit-identical outputs."""
     o = ops()
     dh = 64
     d = H * dh
     g = torch.Generator().manual_seed(5)
     table = torch.randn(n_tiles * 64, 2 * d, generator=g).to(torch.bfloat16).to(DEV)
-    is_live = torch.rand(B, n_tiles, generator=g) < 0.4
-    is_live[0, :3] = torch.tensor([True, False, True])
+    is_live = torch.rand(B, n_tiles, 8, generator=g) < 0.4
+    is_live[0, 0] = torch.tensor([True, False, True, True, False, False, True, False])
     n_l = int(is_live.sum())
-    live = torch.randn((n_l + 3) * 64, 2 * d, generator=g).to(torch.bfloat16).to(DEV)
-    src = torch.empty(B, n_tiles, dtype=torch.int32)
+    live = torch.randn((n_l + 3) * 8, 2 * d, generator=g).to(torch.bfloat16).to(DEV)
+    src = torch.empty(B, n_tiles, 8, dtype=torch.int32)
     perm = torch.randperm(n_l, generator=g)
     k = 0
     for b in range(B):
         for t in range(n_tiles):
-            if is_live[b, t]:
-                src[b, t] = 64 * int(perm[k]); k += 1
-            else:
-                src[b, t] = ~(64 * t)
+            for p in range(8):
+                if is_live[b, t, p]:
+                    src[b, t, p] = 8 * int(perm[k]); k += 1
+                else:
+                    src[b, t, p] = ~(64 * t + 8 * p)
     dense = torch.empty(B, n_tiles * 64, 2 * d, dtype=torch.bfloat16, device=DEV)
     for b in range(B):
         for t in range(n_tiles):
-            r = int(src[b, t])
-            dense[b, 64 * t:64 * t + 64] = live[r:r + 64] if r >= 0 else table[~r:~r + 64]
+            for p in range(8):
+                r = int(src[b, t, p])
+                dense[b, 64 * t + 8 * p:64 * t + 8 * p + 8] = live[r:r + 8] if r >= 0 else table[~r:~r + 8]
     q = torch.randn(B * nq, d, generator=g).to(DEV)
     qb = o.cast(q, qsplit)
     got = o.attention_tiled(qb, live, table, src.to(DEV).contiguous().view(-1), batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=dh,
@@ -208,11 +213,11 @@ def test_tiled_route_is_bit_identical_to_all_tiles_live(prec, monkeypatch):
     assert pipe.vat_lidar._tiled_route_ok(64, h, w)
     a = pipe(pts, off2, patches)
     nl = int(pipe.vat_lidar._last_tile_counts[0])
-    assert 0 < nl < 3 * (h // 8) * (w // 8)
+    assert 0 < nl < 3 * (h // 8) * (w // 8) * 8
     orig = pipe.vat_lidar.forward_pillars
     monkeypatch.setattr(pipe.vat_lidar, "forward_pillars", lambda *x, **k: orig(*x, all_tiles_live=True, **k))
     b = pipe(pts, off2, patches)
-    assert int(pipe.vat_lidar._last_tile_counts[0]) == 3 * (h // 8) * (w // 8)
+    assert int(pipe.vat_lidar._last_tile_counts[0]) == 3 * (h // 8) * (w // 8) * 8
     assert torch.equal(a["lidar_tokens"], b["lidar_tokens"]) and torch.equal(a["fused"], b["fused"])
     monkeypatch.undo()
     # the older (cell-order, untiled) route agrees to the precision mode's tolerance
