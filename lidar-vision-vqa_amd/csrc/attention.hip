@@ -613,15 +613,24 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
         doff[j] = (uint32_t)(row * (isv ? a.ldv : a.ldk) + ((pch ^ f) << 3));
     }
     const int64_t kstep = (int64_t)KVB * a.ldk, vstep = (int64_t)KVB * a.ldv;
-    // tiled stream: lane l keeps the source row of piece (l & 7) of tile tsv_base + (l >> 3); a piece's row is a v_readlane away (no
-    // memory operation in the per-tile path: a scalar load there would sit in lgkmcnt beside the counted LDS waits).  The next
-    // 8 tiles' sources are requested 8 tiles ahead (tsv_nx).
+    // tiled stream: the piece sources of 32 tiles (256 words) sit in an LDS window, two windows deep, filled by wave 0 with ONE
+    // LDS-DMA each (no registers, no vmcnt wait on a VGPR in the loop: fetching the words into registers every 8 tiles made the
+    // compiler drain the K/V requests in flight at every refresh, 21.9 -> 26.9 ms).  A tile's 8 words are read into one VGPR one
+    // tile ahead (lanes 0-7) and a piece's row is a v_readlane away.
     const int32_t *tsrc_b = tiled ? a.tile_src + (int64_t)wave_b * (a.Nkv / KVB) * 8 : nullptr;
-    int tsv_base = 0, tsv = 0, tsv_nx = 0;
-    auto tsv_fetch = [&](int tb) __attribute__((always_inline)) -> int {
-        const int n_e = (a.Nkv / KVB) * 8, e = tb * 8 + lane;
-        return tsrc_b[e < n_e ? e : n_e - 1];
+    int32_t *win = reinterpret_cast<int32_t *>(smem + 3 * TILE_E) + 4;          // [2][256] behind the ring and the redo flag
+    auto win_dma = [&](int w) __attribute__((always_inline)) {                   // wave 0: window w = tiles t0 + 32 w .. + 31
+        const int n_e = (a.Nkv / KVB) * 8;
+        int e = (t0 + 32 * w) * 8 + lane * 4;
+        e = e > n_e - 4 ? n_e - 4 : e;                                          // words past the stream's end are never used
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tsrc_b + e),
+                                         (__attribute__((address_space(3))) void *)(win + (w & 1) * 256), 16, 0, 0);
     };
+    auto win_read = [&](int t) __attribute__((always_inline)) -> int {           // the 8 piece sources of tile t, in lanes 8 k .. 8 k + 7
+        const int r = t - t0;
+        return win[((r >> 5) & 1) * 256 + (r & 31) * 8 + (lane & 7)];
+    };
+    int ps = 0, ps_nx = 0;                                                      // sources of the tile of the next dma() call / the one after
     uint32_t dofft[NPC];                                       // tiled form of doff: row r8 of the piece (the piece's first row is the source row)
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {
@@ -630,7 +639,14 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
         dofft[j] = (uint32_t)(r8 * (isv ? a.ldv : a.ldk) + ((pch ^ f) << 3));
     }
     auto dma = [&](int t, int slot) __attribute__((always_inline)) {
-        if (tiled && t - tsv_base >= 8) { tsv = tsv_nx; tsv_base += 8; tsv_nx = tsv_fetch(tsv_base + 8); }
+        int pcur = 0;
+        if (tiled) {
+            // refill the window two ahead once every wave is 4 tiles into the current one (nobody reads the old buffer any more)
+            if (wid == 0 && ((t - t0) & 31) == 4) win_dma(((t - t0) >> 5) + 1);
+            pcur = ps;
+            ps = ps_nx;
+            ps_nx = win_read(t + 2);
+        }
         const uint16_t *kt = kbase + t * kstep, *vt = vbase + t * vstep;       // wave-uniform (untiled form)
 #pragma unroll
         for (int j = 0; j < NPC; ++j) {
@@ -639,7 +655,7 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
                 const int isv = pc >> 3, piece = pc & 7;
                 const uint16_t *src;
                 if (tiled) {
-                    const int sr = __builtin_amdgcn_readlane(tsv, ((t - tsv_base) << 3) | piece);
+                    const int sr = __builtin_amdgcn_readlane(pcur, piece);
                     const int64_t row = sr >= 0 ? sr : ~sr;
                     src = (isv ? (sr >= 0 ? vbase : vtab) + row * a.ldv : (sr >= 0 ? kbase : ktab) + row * a.ldk) + dofft[j];
                 } else {
@@ -802,7 +818,13 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
     auto stream = [&](auto slow_tag) __attribute__((always_inline)) {
         constexpr bool SLOW = decltype(slow_tag)::value;
         slot = 0;
-        if (tiled) { tsv_base = t0; tsv = tsv_fetch(t0); tsv_nx = tsv_fetch(t0 + 8); }
+        if (tiled) {
+            if (wid == 0) win_dma(0);                          // window 1 follows at tile t0 + 4
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ps = win_read(t0);
+            ps_nx = win_read(t0 + 1);
+        }
         if (t0 < t1) dma(t0, 0);
         if (t0 + 1 < t1) dma(t0 + 1, 1);
         if (t0 + 1 < t1) {                                     // tile t0 landed, tile t0+1 may still fly
@@ -1180,7 +1202,7 @@ extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo,
         if (!arena.ok) return LVQ_EWORKSPACE;
     }
     hipStream_t st = lvq_s(stream);
-    const size_t lds = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16;
+    const size_t lds = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16 + 2 * 256 * sizeof(int32_t);     // ring + redo flag + source windows
     const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
     const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;
     if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
