@@ -531,14 +531,17 @@ __device__ __forceinline__ void lds_tr_wait4(bf16x4 &a, bf16x4 &b, bf16x4 &c, bf
 // the same accumulator -- while K, V and P stay plain bf16.  Rounding Q is the same perturbation for every key of a row, so it
 // does not average out over the stream the way the per-key roundings of K, V and P do (tools/precision_study.py: 2.8e-3 of the
 // 1e-3 budget at 262 144 keys); splitting it costs 4 of 12 MFMAs per 32-key block and 16 VGPRs, nothing in LDS or HBM.
-template <int NW, int QS, int WPS = 3>
-__global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
+template <int NW, int QS, bool TL = false>
+__global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     constexpr int DH = 64, KROW = 64, CH = 8, NT = NW * 64;
     constexpr int NLD = (KVB * CH + NT - 1) / NT;
     constexpr int TILE_E = 2 * KVB * KROW;                     // K + V of one stage (bf16 elements)
     constexpr float THR = 6.0f;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    // wid through readfirstlane: the compiler does not know tid >> 6 is wave-uniform, and everything derived from it (which DMA
+    // piece, K or V, the piece's source row) then turns into exec-masked vector code -- in the tiled stream even a global load of
+    // ldk / ldv with a vmcnt(0) behind it, inside the loop that lives on counted vmcnt
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5, l31 = lane & 31;
     // Workgroup order: hardware deals block ids round-robin over the 8 XCDs, and each XCD has its own L2.  The nqt workgroups
     // that stream the SAME K/V range (same batch, head, split; different query tiles) get block ids 8 apart, i.e. the same XCD
     // back to back, so the range leaves HBM once and the repeats are L2 hits (in plain id order the three copies went to three XCDs).
@@ -596,7 +599,7 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
     // Three LDS slots: tile t+2 is requested at the top of tile t into the slot tile t-1 just left; tile t+1 has landed when a
     // counted vmcnt leaves exactly this wave's newest request in flight.
     const int wave_b = __builtin_amdgcn_readfirstlane(b), wave_hk = __builtin_amdgcn_readfirstlane(hk);
-    const bool tiled = a.tile_src != nullptr;                // kernel-uniform
+    constexpr bool tiled = TL;                               // the tiled key stream of bev_tiles.hip (a.tile_src etc.)
     const uint16_t *kbase = a.k + (tiled ? (int64_t)0 : (int64_t)wave_b * a.k_bs) + (int64_t)wave_hk * a.k_hs;
     const uint16_t *vbase = a.v + (tiled ? (int64_t)0 : (int64_t)wave_b * a.v_bs) + (int64_t)wave_hk * a.v_hs;
     const uint16_t *ktab = tiled ? a.k_tab + (int64_t)wave_hk * a.k_hs : nullptr;
@@ -614,9 +617,9 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
     }
     const int64_t kstep = (int64_t)KVB * a.ldk, vstep = (int64_t)KVB * a.ldv;
     // tiled stream: the piece sources of 32 tiles (256 words) sit in an LDS window, two windows deep, filled by wave 0 with ONE
-    // LDS-DMA each (no registers, no vmcnt wait on a VGPR in the loop: fetching the words into registers every 8 tiles made the
-    // compiler drain the K/V requests in flight at every refresh, 21.9 -> 26.9 ms).  A tile's 8 words are read into one VGPR one
-    // tile ahead (lanes 0-7) and a piece's row is a v_readlane away.
+    // LDS-DMA each (no registers and no vmcnt wait on a VGPR in a loop that lives on counted vmcnt).  A tile's 8 words are read
+    // into one VGPR (lanes 8 k .. 8 k + 7) right after the previous tile's requests went out, and a piece's row is a v_readlane
+    // and a 32 x 32 -> 64-bit scalar multiply away (K and V share one row stride here).
     const int32_t *tsrc_b = tiled ? a.tile_src + (int64_t)wave_b * (a.Nkv / KVB) * 8 : nullptr;
     int32_t *win = reinterpret_cast<int32_t *>(smem + 3 * TILE_E) + 4;          // [2][256] behind the ring and the redo flag
     auto win_dma = [&](int w) __attribute__((always_inline)) {                   // wave 0: window w = tiles t0 + 32 w .. + 31
@@ -630,24 +633,23 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
         const int r = t - t0;
         return win[((r >> 5) & 1) * 256 + (r & 31) * 8 + (lane & 7)];
     };
-    int ps = 0, ps_nx = 0;                                                      // sources of the tile of the next dma() call / the one after
+    int ps = 0;                                                                 // sources of the tile of the next dma() call
+    const uint32_t ld_t = (uint32_t)a.ldk;                                      // tiled: ldk == ldv < 2^31 (checked by the host)
     uint32_t dofft[NPC];                                       // tiled form of doff: row r8 of the piece (the piece's first row is the source row)
+    uint64_t lbj[NPC], xtj[NPC];                               // per DMA piece of this wave: the live base (K or V), live ^ table
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {
         const int pc = wid + NW * j, isv = (pc >> 3) & 1, piece = pc & 7, row = piece * 8 + r8;
         const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
-        dofft[j] = (uint32_t)(r8 * (isv ? a.ldv : a.ldk) + ((pch ^ f) << 3));
+        dofft[j] = (uint32_t)(r8 * ld_t + ((pch ^ f) << 3));
+        const uint64_t lb = reinterpret_cast<uint64_t>(isv ? vbase : kbase), tb = reinterpret_cast<uint64_t>(isv ? vtab : ktab);
+        lbj[j] = lb;
+        xtj[j] = lb ^ tb;
     }
     auto dma = [&](int t, int slot) __attribute__((always_inline)) {
-        int pcur = 0;
-        if (tiled) {
-            // refill the window two ahead once every wave is 4 tiles into the current one (nobody reads the old buffer any more)
-            if (wid == 0 && ((t - t0) & 31) == 4) win_dma(((t - t0) >> 5) + 1);
-            pcur = ps;
-            ps = ps_nx;
-            ps_nx = win_read(t + 2);
-        }
-        const uint16_t *kt = kbase + t * kstep, *vt = vbase + t * vstep;       // wave-uniform (untiled form)
+        // tiled: refill the other window once every wave is 4 tiles into the current one (nobody reads the old buffer any more)
+        if (tiled && wid == 0 && ((t - t0) & 31) == 4) win_dma(((t - t0) >> 5) + 1);
+        const uint16_t *kt = tiled ? nullptr : kbase + t * kstep, *vt = tiled ? nullptr : vbase + t * vstep;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < NPC; ++j) {
             const int pc = wid + NW * j;                       // wave-uniform
@@ -655,9 +657,11 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
                 const int isv = pc >> 3, piece = pc & 7;
                 const uint16_t *src;
                 if (tiled) {
-                    const int sr = __builtin_amdgcn_readlane(pcur, piece);
-                    const int64_t row = sr >= 0 ? sr : ~sr;
-                    src = (isv ? (sr >= 0 ? vbase : vtab) + row * a.ldv : (sr >= 0 ? kbase : ktab) + row * a.ldk) + dofft[j];
+                    // live or table rows by a bitwise mux, not ?: -- a select between the captured pointers becomes a select between
+                    // ADDRESSES inside the closure, which then stays in scratch memory with every value read back as a vector
+                    const int sr = __builtin_amdgcn_readlane(ps, piece), neg = sr >> 31;
+                    const uint64_t roff = (uint64_t)(uint32_t)(sr ^ neg) * ld_t;                  // row sr, or ~sr of the table
+                    src = reinterpret_cast<const uint16_t *>(lbj[j] ^ (xtj[j] & (uint64_t)(int64_t)neg)) + roff + dofft[j];
                 } else {
                     src = (isv ? vt : kt) + doff[j];
                 }
@@ -666,6 +670,7 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
                                                  (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
             }
         }
+        if (tiled) ps = win_read(t + 1);                       // in flight until the next call (LDS returns in order)
     };
     const int my_pieces = (16 - wid + NW - 1) / NW;            // this wave's DMA instructions per tile
 
@@ -823,7 +828,6 @@ __global__ void __launch_bounds__(NW * 64, WPS) k_attn32(AttnArgs a) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             ps = win_read(t0);
-            ps_nx = win_read(t0 + 1);
         }
         if (t0 < t1) dma(t0, 0);
         if (t0 + 1 < t1) dma(t0 + 1, 1);
@@ -1181,7 +1185,7 @@ extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo,
     const int64_t nkv64 = (int64_t)n_tiles * KVB;
     if (nkv64 > 0x7fffffff) return LVQ_EUNSUPPORTED;
     const int nkv = (int)nkv64;
-    if (dh != 64 || (ldq & 7) || (ldkv & 7) || (q_hstride & 7) || (kv_hstride & 7) || (q_bstride & 7) || (ldo & 3) || (o_hstride & 3) || (o_bstride & 3))
+    if (dh != 64 || (ldq & 7) || (ldkv & 7) || ldkv <= 0 || ldkv > 0x7fffffff || (q_hstride & 7) || (kv_hstride & 7) || (q_bstride & 7) || (ldo & 3) || (o_hstride & 3) || (o_bstride & 3))
         return LVQ_EUNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)q_lo | (uintptr_t)k_live | (uintptr_t)v_live | (uintptr_t)k_table | (uintptr_t)v_table) & 15) return LVQ_EUNSUPPORTED;
     if (((uintptr_t)o | (uintptr_t)o_lo) & 7) return LVQ_EUNSUPPORTED;
@@ -1207,11 +1211,11 @@ extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo,
     const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;
     if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
     if (q_lo) {
-        if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 1>), dim3((unsigned)nwg), dim3(384), lds, st, a);
-        else              hipLaunchKernelGGL((k_attn32<4, 1>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+        if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 1, true>), dim3((unsigned)nwg), dim3(384), lds, st, a);
+        else              hipLaunchKernelGGL((k_attn32<4, 1, true>), dim3((unsigned)nwg), dim3(256), lds, st, a);
     } else {
-        if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 0>), dim3((unsigned)nwg), dim3(384), lds, st, a);
-        else              hipLaunchKernelGGL((k_attn32<4, 0>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+        if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 0, true>), dim3((unsigned)nwg), dim3(384), lds, st, a);
+        else              hipLaunchKernelGGL((k_attn32<4, 0, true>), dim3((unsigned)nwg), dim3(256), lds, st, a);
     }
     if (a.nsplit > 1) {
         const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
@@ -1268,9 +1272,7 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
             const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;       // groups padded to the 8 XCDs (see the kernel's id mapping)
             if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
             if (qsplit) {
-                const bool occ2 = getenv("LVQ_ATTN_QS_OCC2") != nullptr;      // experiment knob (256-VGPR build, 2 waves per SIMD)
                 if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 1>), dim3((unsigned)nwg), dim3(384), lds, st, a);
-                else if (occ2)    hipLaunchKernelGGL((k_attn32<4, 1, 2>), dim3((unsigned)nwg), dim3(256), lds, st, a);
                 else              hipLaunchKernelGGL((k_attn32<4, 1>), dim3((unsigned)nwg), dim3(256), lds, st, a);
             } else {
                 if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 0>), dim3((unsigned)nwg), dim3(384), lds, st, a);

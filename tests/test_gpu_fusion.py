@@ -451,12 +451,9 @@ def test_gemm_plain_a_split_w(m, n, k):
     assert (o.to_f32(cb).double().cpu() - ref).abs().max().item() < 1e-2 * scale
 
 
-@pytest.mark.parametrize("B,H,nq,nkv,occ2", [(1, 2, 576, 8192, False), (2, 3, 120, 4096, False), (1, 12, 576, 16384, False),
-                                             (1, 2, 576, 8192, True)])
-def test_attention_stream_q_split(B, H, nq, nkv, occ2, monkeypatch):
+@pytest.mark.parametrize("B,H,nq,nkv", [(1, 2, 576, 8192), (2, 3, 120, 4096), (1, 12, 576, 16384)])
+def test_attention_stream_q_split(B, H, nq, nkv):
     """lvq_attention_bf16 with q = hi + lo, k / v plain (k_attn32<., 1>): exact in Q, bf16 in K, V and P."""
-    if occ2:
-        monkeypatch.setenv("LVQ_ATTN_QS_OCC2", "1")
     o = ops()
     dh = 64
     assert o.attention_stream_ok(nq, nkv, dh) and not o.attention_stream_ok(nq, 196, dh) and not o.attention_stream_ok(nq, nkv, 128)

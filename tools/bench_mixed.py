@@ -63,17 +63,12 @@ def main():
     v1 = (kv1[0][:, d:], None)
     v3 = (kv3[0][:, d:], kv3[1][:, d:])
     res = {}
-    for name, fq, fk, fv, env in (("bf16", q1, kv1, v1, None), ("q-split", q3, kv1, v1, None), ("q-split occ2", q3, kv1, v1, "LVQ_ATTN_QS_OCC2"),
-                                  ("bf16x3", q3, kv3, v3, None)):
-        if env:
-            os.environ[env] = "1"
+    for name, fq, fk, fv in (("bf16", q1, kv1, v1), ("q-split", q3, kv1, v1), ("bf16x3", q3, kv3, v3)):
         t = timeit(lambda: ops.attention(fq, fk, fv, **st), iters=3)
         res[name] = ops.to_f32(ops.attention(fq, fk, fv, **st))
-        if env:
-            del os.environ[env]
         print(f"  {name:12s} {t:8.3f} ms   {fl / t / 1e9:8.1f} TFLOP/s algorithmic")
     ref = res["bf16x3"]
-    for name in ("bf16", "q-split", "q-split occ2"):
+    for name in ("bf16", "q-split"):
         print(f"  max |{name} - bf16x3| = {(res[name] - ref).abs().max().item():.3e}   (|ref| max {ref.abs().max().item():.3f})")
     del kv1, kv3, res
     print(f"--- token kernel (1x1 conv 64 -> 768 + LayerNorm + table), M = {S}*{hw}")
