@@ -13,7 +13,7 @@ all-reduce(SUM) per step of a fused fp32 buffer [token-sum (d) | scene count] (S
 `value` is measured in the precision mode `--precision` (default "mixed": bf16 MFMA tiles everywhere, plain bf16 operands on the
 262 144-key K/V stream, hi + lo bf16 operands elsewhere -- the fastest mode that meets the north-star 1e-3 tolerance, see
 `parity_vs_cpu`, which is measured for EVERY mode timed in this run against the CPU oracle).  Rank 0 prints ONE JSON line with
-`roofline` (dominant kernel: the K|V projection GEMM; algorithmic FLOPs / HIP-event time on the launch stream inside the timed
+`roofline` (dominant kernel: the stream attention or the K|V projection GEMM, whichever took longer; algorithmic FLOPs / HIP-event time on the launch stream inside the timed
 region), `roofline_headline` (the literal "32k pts x 196 patches" cross-attention sub-path), every cross-attention row of
 SURVEY 8d, the HBM-bound voxelisers at cfg-3, the same workload on Dist-U scenes, and `cpu_baseline` (the CPU restatement in
 oracle/ timed on the host cores on a bounded sample).
@@ -241,30 +241,48 @@ def main():
         D.finalize()
         return
 
-    # ---- roofline of the dominant kernel: BEV-token K|V projection GEMM inside VATLiDAR's cross-attention ----
+    # ---- roofline of the two big kernels of VATLiDAR's cross-attention; `roofline` is whichever took longer per launch ----
     h, w = cfg.bev_hw
     d = cfg.d_model
-    per_step = cfg.n_layers + 1        # launches per step: n_layers (VATLiDAR, M = S*HW) + 1 (fusion block, M = S*196); keep the big ones
-    big = [p for i, p in enumerate(events.get("ca_kv_proj", [])) if (i % per_step) < cfg.n_layers]
-    kv_ms = avg_ms(big)
-    # rows the launch actually projects: the tiled key stream computes K|V for the LIVE tiles only (clean tiles come from the
+    per_step = cfg.n_layers + 1        # launches per step: n_layers (VATLiDAR, the S*HW-key stream) + 1 (fusion block, 196 keys); keep the big ones
+    big = lambda tag: [p for i, p in enumerate(events.get(tag, [])) if (i % per_step) < cfg.n_layers]
+    kv_ms, at_ms = avg_ms(big("ca_kv_proj")), avg_ms(big("ca_attn"))
+    # rows the GEMM actually projects: the tiled key stream computes K|V for the LIVE pieces only (clean pieces come from the
     # per-model table) -> EXECUTED rows, read back once after the timed region; the dense routes project every BEV cell
     tc = getattr(pipe.vat_lidar, "_last_tile_counts", None)
     live_rows = int(tc[1]) if tc is not None else S * h * w
     kv_rows = (live_rows + 255) // 256 * 256             # whole 256-row tiles run
     kv_flops = 2.0 * kv_rows * (2 * d) * d               # 4 d^2 per projected key
-    form = {"bf16": "plain operands: 1 MFMA pass", "mixed": "A plain, W hi+lo: 2 MFMA passes (executed FLOPs = 2x algorithmic)",
-            "bf16x3": "A and W hi+lo: 3 MFMA passes (executed FLOPs = 3x algorithmic)"}[args.precision]
-    roofline = None
+    at_flops = 4.0 * S * cfg.n_queries * (h * w) * d     # QK^T + PV over EVERY key (4 nq nkv d per scene)
+    prec = args.precision
+    roofline = roofline_kv = roofline_attn = None
     if kv_ms:
         ach = kv_flops / (kv_ms * 1e-3) / 1e12
-        tr, src = profile_traffic([f"k_gemm_256 M={kv_rows} N={2 * d} K={d} {args.precision}"])
-        roofline = {"bound": "mfma", "kernel": "k_gemm_256 (256x256 tile, LDS-DMA, A ring 3 / W ring 2; VATLiDAR.ca K|V projection over the live key tiles, "
-                    f"M = {kv_rows} of {S * h * w} BEV cells, N=2d, K=d); " + form,
-                    "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "traffic": tr, "traffic_source": src, "avg_launch_ms": round(kv_ms, 4), "flops_per_launch": kv_flops,
-                    "rows_projected": kv_rows, "rows_dense": S * h * w, "live_tile_fraction": round(live_rows / float(S * h * w), 4),
-                    "executed_flops_per_launch": kv_flops * {"bf16": 1, "mixed": 2, "bf16x3": 3}[args.precision]}
+        form = {"bf16": "plain operands: 1 MFMA pass", "mixed": "A plain, W hi+lo: 2 MFMA passes (executed FLOPs = 2x algorithmic)",
+                "bf16x3": "A and W hi+lo: 3 MFMA passes (executed FLOPs = 3x algorithmic)"}[prec]
+        ex = {"bf16": 1, "mixed": 2, "bf16x3": 3}[prec]
+        tr, src = profile_traffic([f"k_gemm_256 M={kv_rows} N={2 * d} K={d} {prec}"])
+        roofline_kv = {"bound": "mfma", "kernel": "k_gemm_256 (256x256 tile, LDS-DMA, A ring 3 / W ring 2; VATLiDAR.ca K|V projection over the live key pieces, "
+                       f"M = {kv_rows} of {S * h * w} BEV cells, N=2d, K=d); " + form,
+                       "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                       "traffic": tr, "traffic_source": src, "avg_launch_ms": round(kv_ms, 4), "flops_per_launch": kv_flops,
+                       "rows_projected": kv_rows, "rows_dense": S * h * w, "live_fraction": round(live_rows / float(S * h * w), 4),
+                       "executed_flops_per_launch": kv_flops * ex, "achieved_executed": round(ach * ex, 2),
+                       "frac_executed": round(ach * ex / PEAK_BF16_TFLOPS, 4)}
+    if at_ms:
+        ach = at_flops / (at_ms * 1e-3) / 1e12
+        form = {"bf16": "Q, K, P, V plain: 1 MFMA pass", "mixed": "Q hi+lo (2 MFMA passes over QK^T), K, P, V plain: executed FLOPs = 1.5x algorithmic",
+                "bf16x3": "all operands hi+lo: executed FLOPs = 3x algorithmic"}[prec]
+        ex = {"bf16": 1.0, "mixed": 1.5, "bf16x3": 3.0}[prec]
+        tr, src = profile_traffic([f"k_attn32 S={S} nq={cfg.n_queries} nkv={h * w} {prec}"])
+        roofline_attn = {"bound": "mfma", "kernel": f"k_attn32 (VATLiDAR.ca: {S} scenes x {cfg.n_heads} heads x {cfg.n_queries} queries over the {h * w}-key "
+                         "BEV stream, head_dim 64; 32x32x16 MFMA, LDS-DMA ring of 3 K|V tiles, fixed softmax reference); " + form,
+                         "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                         "traffic": tr, "traffic_source": src, "avg_launch_ms": round(at_ms, 4), "flops_per_launch": at_flops,
+                         "executed_flops_per_launch": at_flops * ex, "achieved_executed": round(ach * ex, 2),
+                         "frac_executed": round(ach * ex / PEAK_BF16_TFLOPS, 4)}
+    if roofline_kv or roofline_attn:
+        roofline = roofline_attn if (at_ms or 0) >= (kv_ms or 0) else roofline_kv
 
     result = {
         "metric": "fused tokens/sec/GPU + cross-attn MFMA-roofline % (32k pts x 196 patches)",
@@ -274,7 +292,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: " + cfg.describe(), "scenes_per_gpu_per_step": S,
                    "fused_tokens_per_scene": cfg.n_queries, "parallelism": f"scene-parallel x{world}",
                    "precision_mode": args.precision + " (bf16 MFMA tiles throughout; see parity_vs_cpu for the error of every mode)"},
-        "roofline": roofline,
+        "roofline": roofline, "roofline_kv_proj": roofline_kv, "roofline_attention": roofline_attn,
     }
 
     mode_values = {args.precision: round(value, 1)}

@@ -176,11 +176,22 @@ def main():
     for name, groups in MIXED_CANDIDATES.items():
         out, lt, dt = run(groups)
         print(f"{name:60s} fused err {(out - ref).abs().max().item():.3e}   lidar-token err {(lt - ref_lt).abs().max().item():.3e}", flush=True)
-    # scores in fp16 (Q and K rounded to 11 bits instead of 8; same MFMA rate): how much of the Q-side error is left?
-    F16.update(["lidar.ca.q", "lidar.ca.kv"])
-    out, lt, dt = run(["stream: BEV tokens x (A of K|V proj)", "stream: P (softmax numerators)"])
-    F16.clear()
-    print(f"{'x, P bf16; Q, K, V fp16; everything else exact':60s} fused err {(out - ref).abs().max().item():.3e}   lidar-token err {(lt - ref_lt).abs().max().item():.3e}", flush=True)
+    # fp16 forms (11-bit significand, same MFMA rate as bf16, ONE product instead of the two of hi + lo): which operands can take it?
+    F16_CANDIDATES = {
+        "x, P bf16; Q, K, V fp16; rest exact": (["lidar.ca.q", "lidar.ca.kv"], ["stream: BEV tokens x (A of K|V proj)", "stream: P (softmax numerators)"]),
+        "P, V... bf16 stream, Q fp16 (single), rest exact": (["lidar.ca.q"], RANDOM_PER_KEY),
+        "x, K, V, P bf16; W_k|W_v fp16 (single); rest exact": (["lidar.ca.kv_w"], RANDOM_PER_KEY),
+        "x, W_k|W_v, K, Q fp16; V, P bf16; rest exact": (["lidar.ca.kv_in", "lidar.ca.kv_w", "lidar.ca.q"], ["stream: K, V", "stream: P (softmax numerators)"]),
+        "t, W_proj, x, W_k|W_v, Q fp16; K, V, P bf16; rest exact": (["lidar.t", "lidar.w_proj", "lidar.ca.kv_in", "lidar.ca.kv_w", "lidar.ca.q"],
+                                                                   ["stream: K, V", "stream: P (softmax numerators)"]),
+        "t, W_proj, x, W_k|W_v, K, V, Q fp16; P bf16; rest exact": (["lidar.t", "lidar.w_proj", "lidar.ca.kv_in", "lidar.ca.kv_w", "lidar.ca.q", "lidar.ca.kv"],
+                                                                   ["stream: P (softmax numerators)"]),
+    }
+    for name, (f16, groups) in F16_CANDIDATES.items():
+        F16.update(f16)
+        out, lt, dt = run(groups)
+        F16.clear()
+        print(f"{name:60s} fused err {(out - ref).abs().max().item():.3e}   lidar-token err {(lt - ref_lt).abs().max().item():.3e}", flush=True)
     out, lt, dt = run(list(GROUPS))
     print(f"{'everything bf16':60s} fused err {(out - ref).abs().max().item():.3e}   lidar-token err {(lt - ref_lt).abs().max().item():.3e}", flush=True)
 
