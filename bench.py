@@ -274,11 +274,20 @@ def main():
         form = {"bf16": "Q, K, P, V plain: 1 MFMA pass", "mixed": "Q hi+lo (2 MFMA passes over QK^T), K, P, V plain: executed FLOPs = 1.5x algorithmic",
                 "bf16x3": "all operands hi+lo: executed FLOPs = 3x algorithmic"}[prec]
         ex = {"bf16": 1.0, "mixed": 1.5, "bf16x3": 3.0}[prec]
+        # keys the launch actually streams: block 0's queries are scene-independent, so a scene streams only its live pieces, twice
+        # (live rows added, the table rows at their positions subtracted from the per-model totals) -- read back after the timed region
+        pi = getattr(pipe.vat_lidar.blocks[0], "_last_pair_info", None)
+        keys_streamed = S * h * w
+        if pi is not None:
+            pin = pi.cpu().numpy()
+            keys_streamed = int(sum(int(t) * 64 if int(u) else h * w for t, u in pin))
+            form += f"; signed pair stream: {keys_streamed} of {S * h * w} keys streamed ({sum(int(u) for _, u in pin)} of {S} scenes signed)"
+        ex *= keys_streamed / float(S * h * w)
         tr, src = profile_traffic([f"k_attn32 S={S} nq={cfg.n_queries} nkv={h * w} {prec}"])
         roofline_attn = {"bound": "mfma", "kernel": f"k_attn32 (VATLiDAR.ca: {S} scenes x {cfg.n_heads} heads x {cfg.n_queries} queries over the {h * w}-key "
                          "BEV stream, head_dim 64; 32x32x16 MFMA, LDS-DMA ring of 3 K|V tiles, fixed softmax reference); " + form,
                          "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                         "traffic": tr, "traffic_source": src, "avg_launch_ms": round(at_ms, 4), "flops_per_launch": at_flops,
+                         "traffic": tr, "traffic_source": src, "avg_launch_ms": round(at_ms, 4), "flops_per_launch": at_flops, "keys_streamed": keys_streamed,
                          "executed_flops_per_launch": at_flops * ex, "achieved_executed": round(ach * ex, 2),
                          "frac_executed": round(ach * ex / PEAK_BF16_TFLOPS, 4)}
     if roofline_kv or roofline_attn:

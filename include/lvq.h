@@ -222,12 +222,13 @@ size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, int nkv, in
  * Rows >= *n_voxels_dev (if given) are ignored. */
 int lvq_pillar_index_map(const int32_t *coords_bzyx, int64_t m_cap, const int32_t *n_voxels_dev, int batch, int ny, int nx,
                          int32_t *idx_map, lvq_stream_t stream);
-/* Tile bookkeeping.  ny, nx multiples of 8; nt = (ny/8)(nx/8) tiles per scene.
- *   live_list [batch * nt]   code t * batch + s of the k-th live tile, in (tile, scene) order
- *   tile_src  [batch * nt]   per (scene s, tile t) at s * nt + t: 64 k (first row of the tile among the live rows) or ~(64 t)
- *                            (first row of the tile in the table) when the tile is clean
- *   counts    [2]            live tiles, live rows (= 64 x)
- * force_all != 0 marks every tile live (table build; dense comparator). */
+/* Piece bookkeeping.  ny, nx multiples of 8; nt = (ny/8)(nx/8) tiles of 8 x 8 cells per scene, each made of eight 2 x 4-cell
+ * PIECES (piece p: row pair p >> 1, column half p & 1; 8 keys).  A piece is live when its 4 x 6-cell halo holds a pillar.
+ *   live_list [batch * nt * 8]   code (t * batch + s) * 8 + p of the k-th live piece, in (tile, scene, piece) order
+ *   tile_src  [batch * nt * 8]   per (scene s, tile t, piece p) at (s * nt + t) * 8 + p: 8 k (first row of the piece among the live
+ *                                rows) or ~(64 t + 8 p) (its first row in the table) when the piece is clean
+ *   counts    [2]                live pieces, live rows (= 8 x)
+ * force_all != 0 marks every piece live (table build; dense comparator). */
 size_t lvq_bev_tiles_workspace_bytes(int batch, int ny, int nx);
 int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, int force_all, int32_t *live_list, int32_t *tile_src,
                   int32_t *counts, void *ws, size_t ws_bytes, lvq_stream_t stream);
@@ -245,14 +246,40 @@ int lvq_bev_tile_tokens(const float *pillar_feat, const int32_t *idx_map, const 
 int lvq_gemm_bf16_live_rows(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,
                             int64_t m_cap, const int32_t *m_rows_dev, int n, int k, int64_t lda, int64_t ldw, int64_t ldc,
                             lvq_bf16 *c_bf16, lvq_bf16 *c_lo, lvq_stream_t stream);
-/* softmax(q K^T * scale) V over the tiled stream: batch b reads tile t from row tile_src[b * n_tiles + t] of k_live / v_live when
- * that is >= 0, from row ~tile_src of k_table / v_table otherwise.  Shapes of lvq_attention_stream_ok(nq, 64 * n_tiles, 64) only;
+/* softmax(q K^T * scale) V over the tiled stream: batch b reads the 8 rows of piece p of tile t from row
+ * tile_src[(b * n_tiles + t) * 8 + p] of k_live / v_live when that is >= 0, from row ~tile_src of k_table / v_table otherwise.  Shapes of lvq_attention_stream_ok(nq, 64 * n_tiles, 64) only;
  * q plain or hi + lo (mixed mode), K / V plain.  Workspace: lvq_attention_workspace_bytes(batch, n_heads, nq, 64 * n_tiles, 64, 1). */
 int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_live, const lvq_bf16 *v_live,
                              const lvq_bf16 *k_table, const lvq_bf16 *v_table, const int32_t *tile_src, int batch, int n_heads, int nq,
                              int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv, int64_t kv_hstride,
                              int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o, lvq_bf16 *o_lo, void *ws,
                              size_t ws_bytes, lvq_stream_t stream);
+
+/* Attention over the LIVE pieces only, for queries that do not depend on the batch (VATLiDAR's first block, vat_lidar.py:259-270 (q = self.query expanded over the batch + view embedding) and 283-288 (blocks) +
+ * vat_blocks.py:37-42: learned queries -> self-attention -> ca_ln -> W_q).  With the fixed softmax reference the contribution of a
+ * table key to (l, O) is then the same for every batch, so  result = TOTALS(all table keys) - table terms at the batch's live
+ * positions + its live rows: a stream over 2 x (live fraction) of the keys.
+ *   lvq_attention_bf16_stream_totals: totals [n_heads, nq, dh + 2] fp32 = unnormalised (O | m | l) of ONE batch of queries over a
+ *       dense key stream (the per-model K | V table); once per weights version.
+ *   lvq_bev_scene_pairs: pair_src [batch, cap_tiles, 8], pair_info [batch, 2] from lvq_bev_tiles' tile_src -- tile j of a batch holds
+ *       its live pieces 4 j .. 4 j + 3 (keys 0..31, added) and the table rows at their positions (keys 32..63, subtracted);
+ *       pair_info[2 b] = pair tiles, pair_info[2 b + 1] = 1 when that is shorter than the full stream (else the batch runs tile_src).
+ *   lvq_attention_bf16_tiled_signed: as lvq_attention_bf16_tiled (same q as the totals; q_bstride = 0 shares one copy).  A
+ *       (batch, head) whose signed row sum is not finite or below 1/16 of the table total is redone over its full stream by a
+ *       predicated second launch.  Not bit-identical to the full stream (fp32 accumulation order); same operand roundings. */
+size_t lvq_attention_stream_totals_workspace_bytes(int n_heads, int nq, int nkv, int dh);
+int lvq_attention_bf16_stream_totals(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k, const lvq_bf16 *v, int n_heads, int nq,
+                                     int nkv, int dh, int64_t ldq, int64_t q_hstride, int64_t ldkv, int64_t kv_hstride, float scale,
+                                     float *totals, void *ws, size_t ws_bytes, lvq_stream_t stream);
+int lvq_bev_scene_pairs(const int32_t *tile_src, int batch, int n_tiles, int cap_tiles, int32_t *pair_src, int32_t *pair_info,
+                        lvq_stream_t stream);
+size_t lvq_attention_tiled_signed_workspace_bytes(int batch, int n_heads, int nq, int n_tiles, int dh);
+int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_live, const lvq_bf16 *v_live,
+                                    const lvq_bf16 *k_table, const lvq_bf16 *v_table, const int32_t *tile_src, const int32_t *pair_src,
+                                    const int32_t *pair_info, int pair_cap_tiles, const float *totals, int batch, int n_heads, int nq,
+                                    int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv,
+                                    int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o,
+                                    lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream);
 
 /* 1 when the long-stream kernel takes (nq, nkv, dh) without bias / mask: head_dim 64, nkv >= 4096 and a multiple of 64, query
  * count with at most 1/8 padding to 128 / 192 rows.  Those are the shapes for which lvq_attention_bf16 accepts the "mixed" operand

@@ -42,6 +42,15 @@ struct AttnArgs {
     // and at row ~tile_src of k_tab / v_tab otherwise
     const int32_t *tile_src;
     const uint16_t *k_tab, *v_tab;
+    // signed pair stream (k_attn32<., ., 2>, lvq_attention_bf16_tiled_signed): batch b with pair_info[2 b + 1] != 0 streams the
+    // pair_info[2 b] tiles of pair_src + b * pair_cap * 8 (bev_tiles.hip: k_scene_pairs) and SUBTRACTS keys 32..63 of every tile; the
+    // per-model totals (unnormalised O | m | l per head and query, shared by all batches) are added by the combine kernel
+    const int32_t *pair_src, *pair_info;
+    int pair_cap;
+    const float *totals;
+    int32_t *flags;           // out, per (b, h): the signed result of some query is unusable (non-finite, or cancellation too deep)
+    const int32_t *pred;      // in, per (b, h): workgroups / rows of (b, h) with pred == 0 do nothing (the predicated full re-run)
+    int force_part;           // write partials even when nsplit == 1
 };
 
 constexpr int KVB = 64;  // keys per tile
@@ -531,7 +540,7 @@ __device__ __forceinline__ void lds_tr_wait4(bf16x4 &a, bf16x4 &b, bf16x4 &c, bf
 // the same accumulator -- while K, V and P stay plain bf16.  Rounding Q is the same perturbation for every key of a row, so it
 // does not average out over the stream the way the per-key roundings of K, V and P do (tools/precision_study.py: 2.8e-3 of the
 // 1e-3 budget at 262 144 keys); splitting it costs 4 of 12 MFMAs per 32-key block and 16 VGPRs, nothing in LDS or HBM.
-template <int NW, int QS, bool TL = false>
+template <int NW, int QS, int TL = 0>
 __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     constexpr int DH = 64, KROW = 64, CH = 8, NT = NW * 64;
     constexpr int NLD = (KVB * CH + NT - 1) / NT;
@@ -550,6 +559,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     if (grp >= a.B * a.H * a.nsplit) return;                    // padding of the group count to a multiple of 8 (whole workgroup)
     const int sp = grp % a.nsplit, h = (grp / a.nsplit) % a.H, b = grp / (a.nsplit * a.H);
     const int hk = h / (a.H / a.Hkv);
+    if (a.pred && a.pred[b * a.H + h] == 0) return;             // predicated re-run: nothing to redo for this (batch, head)
     const int q0 = qtile * (NW * 32) + wid * 32;
     const int qi = q0 + l31;
     const float cexp0 = a.scale * 1.4426950408889634f;
@@ -586,9 +596,13 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
     float mref = 0.f, lsum = 0.f;
+    float lsum1 = 0.f;                                          // TL == 2: row sum of keys 32..63 of every tile (the subtracted half)
     bool fresh = true;
 
-    const int n_tiles = a.Nkv / KVB;
+    // TL == 2: this batch's stream is its pair list (signed) or, when that would not be shorter, its full tile list (unsigned)
+    const int pair_mode = TL == 2 ? __builtin_amdgcn_readfirstlane(a.pair_info[2 * b + 1]) : 0;
+    const uint32_t smask = pair_mode ? 0x80008000u : 0u;        // sign bits of a packed bf16 pair
+    const int n_tiles = pair_mode ? __builtin_amdgcn_readfirstlane(a.pair_info[2 * b]) : a.Nkv / KVB;
     const int tps = (n_tiles + a.nsplit - 1) / a.nsplit;
     const int t0 = sp * tps;
     const int t1 = t0 + tps < n_tiles ? t0 + tps : n_tiles;
@@ -599,7 +613,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     // Three LDS slots: tile t+2 is requested at the top of tile t into the slot tile t-1 just left; tile t+1 has landed when a
     // counted vmcnt leaves exactly this wave's newest request in flight.
     const int wave_b = __builtin_amdgcn_readfirstlane(b), wave_hk = __builtin_amdgcn_readfirstlane(hk);
-    constexpr bool tiled = TL;                               // the tiled key stream of bev_tiles.hip (a.tile_src etc.)
+    constexpr bool tiled = TL != 0;                          // the tiled key stream of bev_tiles.hip (a.tile_src etc.)
     const uint16_t *kbase = a.k + (tiled ? (int64_t)0 : (int64_t)wave_b * a.k_bs) + (int64_t)wave_hk * a.k_hs;
     const uint16_t *vbase = a.v + (tiled ? (int64_t)0 : (int64_t)wave_b * a.v_bs) + (int64_t)wave_hk * a.v_hs;
     const uint16_t *ktab = tiled ? a.k_tab + (int64_t)wave_hk * a.k_hs : nullptr;
@@ -620,10 +634,10 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     // LDS-DMA each (no registers and no vmcnt wait on a VGPR in a loop that lives on counted vmcnt).  A tile's 8 words are read
     // into one VGPR (lanes 8 k .. 8 k + 7) right after the previous tile's requests went out, and a piece's row is a v_readlane
     // and a 32 x 32 -> 64-bit scalar multiply away (K and V share one row stride here).
-    const int32_t *tsrc_b = tiled ? a.tile_src + (int64_t)wave_b * (a.Nkv / KVB) * 8 : nullptr;
+    const int32_t *tsrc_b = !tiled ? nullptr : pair_mode ? a.pair_src + (int64_t)wave_b * a.pair_cap * 8 : a.tile_src + (int64_t)wave_b * (a.Nkv / KVB) * 8;
     int32_t *win = reinterpret_cast<int32_t *>(smem + 3 * TILE_E) + 4;          // [2][256] behind the ring and the redo flag
     auto win_dma = [&](int w) __attribute__((always_inline)) {                   // wave 0: window w = tiles t0 + 32 w .. + 31
-        const int n_e = (a.Nkv / KVB) * 8;
+        const int n_e = n_tiles * 8;
         int e = (t0 + 32 * w) * 8 + lane * 4;
         e = e > n_e - 4 ? n_e - 4 : e;                                          // words past the stream's end are never used
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tsrc_b + e),
@@ -780,8 +794,9 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
                 const float x0 = fast_exp2(sc[2 * e]), x1 = fast_exp2(sc[2 * e + 1]);
                 ls += x0 + x1;
                 pk[e] = pack_bf16(x0, x1);
+                if (TL == 2 && kb == 1) pk[e] ^= smask;        // -P for the subtracted half of a pair tile
             }
-            lsum += ls;
+            if (TL == 2 && kb == 1) lsum1 += ls; else lsum += ls;
             uint4 u0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), u1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             const bf16x8 pf0 = *reinterpret_cast<bf16x8 *>(&u0), pf1 = *reinterpret_cast<bf16x8 *>(&u1);
             lds_tr_wait4(a00, a01, a10, a11);
@@ -823,7 +838,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     auto stream = [&](auto slow_tag) __attribute__((always_inline)) {
         constexpr bool SLOW = decltype(slow_tag)::value;
         slot = 0;
-        if (tiled) {
+        if (tiled && t0 < t1) {                                // (an empty range reads nothing: a pair list may have no tiles at all)
             if (wid == 0) win_dma(0);                          // window 1 follows at tile t0 + 4
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -885,7 +900,8 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     if (tid == 0) *redo_flag = 0;
     stream(std::false_type{});
     fresh = !(t0 < t1);
-    if (t0 < t1) {
+    if (TL == 2) lsum = pair_mode ? lsum - lsum1 : lsum + lsum1;
+    if (t0 < t1 && !pair_mode) {                                // a signed partial may be anything; the combine kernel judges the total
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
         const float ltot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         if (!(ltot < 1.2676506e30f) || !(ltot > 7.8886091e-31f)) *redo_flag = 1;      // outside [2^-100, 2^100]; also catches inf / NaN
@@ -896,7 +912,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
-        lsum = 0.f; mref = 0.f; fresh = true;
+        lsum = 0.f; lsum1 = 0.f; mref = 0.f; fresh = true;
         stream(std::true_type{});
     }
 
@@ -906,7 +922,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
         lsum = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     if (qi >= a.Nq) return;
-    if (a.nsplit > 1) {
+    if (a.nsplit > 1 || a.force_part) {
         float *pr = a.part + ((((int64_t)b * a.H + h) * a.nsplit + sp) * a.Nq + qi) * (a.dh + 2);
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -975,6 +991,84 @@ __global__ void __launch_bounds__(256) k_attn_combine(AttnArgs a) {
                               pack_bf16(y[2] - __uint_as_float(hv.y << 16), y[3] - __uint_as_float(hv.y & 0xffff0000u)));
         *reinterpret_cast<uint2 *>(a.ol + off) = lv;
     }
+}
+
+// Signed pair stream (k_attn32<., ., 2>): merge the KV splits of (b, h), add the per-model totals when the batch ran its pair list,
+// normalise -- and JUDGE the result: a signed sum is only as good as what is left after the subtraction.  With T the total row sum
+// over all table keys and l the final one, fp32 accumulation error is ~2^-20 T, so l < T / 16 (or a non-finite / non-positive l)
+// flags (b, h) for the predicated full re-run.  With pred set this is that re-run's merge (rows of unflagged (b, h) are left alone).
+__global__ void __launch_bounds__(256) k_attn_combine_signed(AttnArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int dq = a.dh / 4;
+    const int64_t total = (int64_t)a.B * a.H * a.Nq * dq;
+    if (idx >= total) return;
+    const int d0 = (int)(idx % dq) * 4;
+    const int64_t row = idx / dq;                    // (b*H + h)*Nq + qi
+    const int qi = (int)(row % a.Nq);
+    const int64_t bh = row / a.Nq;
+    const int h = (int)(bh % a.H), b = (int)(bh / a.H);
+    if (a.pred && a.pred[bh] == 0) return;
+    const int stride = a.dh + 2;
+    const bool signed_b = !a.pred && a.pair_info && a.pair_info[2 * b + 1] != 0;
+    const float *tot = signed_b ? a.totals + ((int64_t)h * a.Nq + qi) * stride : nullptr;
+    float M = tot ? tot[a.dh] : -INFINITY;
+    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, a.part[((bh * a.nsplit + s) * a.Nq + qi) * stride + a.dh]);
+    const float Ms = (M == -INFINITY) ? 0.f : M;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, l = 0.f, lt = 0.f;
+    if (tot) {
+        const float w = exp2f(tot[a.dh] - Ms);
+        lt = w * tot[a.dh + 1];
+        l = lt;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = w * tot[d0 + r];
+    }
+    for (int s = 0; s < a.nsplit; ++s) {
+        const float *pr = a.part + ((bh * a.nsplit + s) * a.Nq + qi) * stride;
+        const float w = exp2f(pr[a.dh] - Ms);
+        l += w * pr[a.dh + 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += w * pr[d0 + r];
+    }
+    if (signed_b && d0 == 0 && a.flags && !(l > 0.0625f * lt && l < 3.0e38f)) a.flags[bh] = 1;
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    float y[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = acc[r] * inv;
+    const int64_t off = (int64_t)b * a.o_bs + (int64_t)qi * a.ldo + (int64_t)h * a.o_hs + d0;
+    uint2 hv = make_uint2(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]));
+    *reinterpret_cast<uint2 *>(a.o + off) = hv;
+    if (a.ol) {
+        uint2 lv = make_uint2(pack_bf16(y[0] - __uint_as_float(hv.x << 16), y[1] - __uint_as_float(hv.x & 0xffff0000u)),
+                              pack_bf16(y[2] - __uint_as_float(hv.y << 16), y[3] - __uint_as_float(hv.y & 0xffff0000u)));
+        *reinterpret_cast<uint2 *>(a.ol + off) = lv;
+    }
+}
+
+// merge the KV splits of a B = 1 run WITHOUT normalising: totals[h][qi] = (sum_s w_s O_s | M | sum_s w_s l_s)
+__global__ void __launch_bounds__(256) k_attn_combine_raw(AttnArgs a, float *__restrict__ totals) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int dq = a.dh / 4;
+    const int64_t total = (int64_t)a.B * a.H * a.Nq * dq;
+    if (idx >= total) return;
+    const int d0 = (int)(idx % dq) * 4;
+    const int64_t row = idx / dq;
+    const int qi = (int)(row % a.Nq);
+    const int64_t bh = row / a.Nq;
+    const int stride = a.dh + 2;
+    float M = -INFINITY;
+    for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, a.part[((bh * a.nsplit + s) * a.Nq + qi) * stride + a.dh]);
+    const float Ms = (M == -INFINITY) ? 0.f : M;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, l = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) {
+        const float *pr = a.part + ((bh * a.nsplit + s) * a.Nq + qi) * stride;
+        const float w = exp2f(pr[a.dh] - Ms);
+        l += w * pr[a.dh + 1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += w * pr[d0 + r];
+    }
+    float *dst = totals + (bh * a.Nq + qi) * stride;
+    *reinterpret_cast<f32x4 *>(dst + d0) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    if (d0 == 0) { dst[a.dh] = Ms; dst[a.dh + 1] = l; }
 }
 
 // launch geometry shared by lvq_attention_workspace_bytes and lvq_attention_bf16
@@ -1190,7 +1284,7 @@ extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo,
     if (((uintptr_t)q | (uintptr_t)q_lo | (uintptr_t)k_live | (uintptr_t)v_live | (uintptr_t)k_table | (uintptr_t)v_table) & 15) return LVQ_EUNSUPPORTED;
     if (((uintptr_t)o | (uintptr_t)o_lo) & 7) return LVQ_EUNSUPPORTED;
     if (n_heads > 65535 || batch > 65535) return LVQ_EUNSUPPORTED;
-    AttnArgs a;
+    AttnArgs a{};
     a.q = q; a.ql = q_lo; a.k = k_live; a.kl = nullptr; a.v = v_live; a.vl = nullptr; a.bias = nullptr;
     a.B = batch; a.H = n_heads; a.Hkv = n_heads; a.Nq = nq; a.Nkv = nkv; a.dh = dh;
     a.q_bs = q_bstride; a.ldq = ldq; a.q_hs = q_hstride; a.k_bs = 0; a.ldk = ldkv; a.k_hs = kv_hstride;
@@ -1211,16 +1305,130 @@ extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo,
     const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;
     if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
     if (q_lo) {
-        if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 1, true>), dim3((unsigned)nwg), dim3(384), lds, st, a);
-        else              hipLaunchKernelGGL((k_attn32<4, 1, true>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+        if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 1, 1>), dim3((unsigned)nwg), dim3(384), lds, st, a);
+        else              hipLaunchKernelGGL((k_attn32<4, 1, 1>), dim3((unsigned)nwg), dim3(256), lds, st, a);
     } else {
-        if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 0, true>), dim3((unsigned)nwg), dim3(384), lds, st, a);
-        else              hipLaunchKernelGGL((k_attn32<4, 0, true>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+        if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 0, 1>), dim3((unsigned)nwg), dim3(384), lds, st, a);
+        else              hipLaunchKernelGGL((k_attn32<4, 0, 1>), dim3((unsigned)nwg), dim3(256), lds, st, a);
     }
     if (a.nsplit > 1) {
         const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
         hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
     }
+    return lvq_launch_status();
+}
+
+namespace {
+template <int TL> void launch_k32(const AttnArgs &a, int nw, bool qs, int64_t nwg, size_t lds, hipStream_t st) {
+    if (qs) {
+        if (nw == 6) hipLaunchKernelGGL((k_attn32<6, 1, TL>), dim3((unsigned)nwg), dim3(384), lds, st, a);
+        else         hipLaunchKernelGGL((k_attn32<4, 1, TL>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    } else {
+        if (nw == 6) hipLaunchKernelGGL((k_attn32<6, 0, TL>), dim3((unsigned)nwg), dim3(384), lds, st, a);
+        else         hipLaunchKernelGGL((k_attn32<4, 0, TL>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    }
+}
+}  // namespace
+
+// ---- the signed pair stream: attention over the LIVE pieces only -------------------------------------------------------------
+// When the queries do not depend on the batch (VATLiDAR's first block: learned queries -> self-attention -> ca_ln -> W_q), the
+// contribution of a TABLE key to the fixed-reference softmax sums (l, O) is the same for every batch.  With TOTALS = the sums over
+// all table keys (once per model: lvq_attention_bf16_stream_totals), a batch's result is
+//     TOTALS - sum over its live positions of the table contribution + sum over its live rows,
+// i.e. a stream over 2 x (live fraction) of the keys instead of all of them.  The subtracted terms are recomputed with the same
+// operand bits as inside TOTALS, so the cancellation is exact up to fp32 accumulation order.  Batches whose pair list would not be
+// shorter run their full tile list; (batch, head) pairs whose signed result is unusable are redone by a predicated full launch.
+
+// totals [n_heads, nq, dh + 2] fp32 (unnormalised O | m | l) of ONE batch of queries over a dense key stream (the table).
+extern "C" size_t lvq_attention_stream_totals_workspace_bytes(int n_heads, int nq, int nkv, int dh) {
+    const AttnPlan pl = plan_attn(1, n_heads, nq, nkv, dh, false, true);
+    if (!pl.k32) return 0;
+    return (size_t)n_heads * pl.nsplit * nq * (dh + 2) * sizeof(float) + 256;
+}
+extern "C" int lvq_attention_bf16_stream_totals(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k, const lvq_bf16 *v, int n_heads, int nq,
+                                                int nkv, int dh, int64_t ldq, int64_t q_hstride, int64_t ldkv, int64_t kv_hstride, float scale,
+                                                float *totals, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+    if (n_heads <= 0 || nq <= 0 || nkv <= 0 || !q || !k || !v || !totals) return LVQ_EINVAL;
+    if (dh != 64 || (ldq & 7) || (ldkv & 7) || (q_hstride & 7) || (kv_hstride & 7) || n_heads > 65535) return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)q | (uintptr_t)q_lo | (uintptr_t)k | (uintptr_t)v | (uintptr_t)totals) & 15) return LVQ_EUNSUPPORTED;
+    if (((int64_t)nkv * ldkv + dh) * 2 >= (1ll << 32)) return LVQ_EUNSUPPORTED;
+    const AttnPlan pl = plan_attn(1, n_heads, nq, nkv, dh, false, true);
+    if (!pl.k32) return LVQ_EUNSUPPORTED;
+    AttnArgs a{};
+    a.q = q; a.ql = q_lo; a.k = k; a.v = v;
+    a.B = 1; a.H = n_heads; a.Hkv = n_heads; a.Nq = nq; a.Nkv = nkv; a.dh = dh;
+    a.ldq = ldq; a.q_hs = q_hstride; a.ldk = ldkv; a.k_hs = kv_hstride; a.ldv = ldkv; a.v_hs = kv_hstride;
+    a.scale = scale; a.nsplit = pl.nsplit; a.nqt = pl.nqt; a.force_part = 1;
+    LvqArena arena(ws, ws_bytes);
+    a.part = arena.take<float>((size_t)n_heads * pl.nsplit * nq * (dh + 2));
+    if (!arena.ok) return LVQ_EWORKSPACE;
+    hipStream_t st = lvq_s(stream);
+    const size_t lds = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16;
+    const int64_t ngrp = (int64_t)a.H * a.nsplit;
+    launch_k32<0>(a, pl.k32, q_lo != nullptr, (ngrp + 7) / 8 * 8 * a.nqt, lds, st);
+    const int64_t total = (int64_t)a.H * a.Nq * (a.dh / 4);
+    hipLaunchKernelGGL(k_attn_combine_raw, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a, totals);
+    return lvq_launch_status();
+}
+
+extern "C" size_t lvq_attention_tiled_signed_workspace_bytes(int batch, int n_heads, int nq, int n_tiles, int dh) {
+    const int64_t nkv = (int64_t)n_tiles * KVB;
+    if (nkv > 0x7fffffff) return 0;
+    const AttnPlan pl = plan_attn(batch, n_heads, nq, (int)nkv, dh, false, true);
+    if (!pl.k32) return 0;
+    return (size_t)batch * n_heads * pl.nsplit * nq * (dh + 2) * sizeof(float) + (size_t)batch * n_heads * sizeof(int32_t) + 512;
+}
+
+// As lvq_attention_bf16_tiled, with the per-batch pair lists of lvq_bev_scene_pairs and the per-model totals.  The queries must be the
+// ones the totals were computed with (pass q_bstride = 0 to share one copy between the batches).
+extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_live, const lvq_bf16 *v_live,
+                                               const lvq_bf16 *k_table, const lvq_bf16 *v_table, const int32_t *tile_src, const int32_t *pair_src,
+                                               const int32_t *pair_info, int pair_cap_tiles, const float *totals, int batch, int n_heads, int nq,
+                                               int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv,
+                                               int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o,
+                                               lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+    if (batch <= 0 || n_heads <= 0 || nq < 0 || n_tiles <= 0 || pair_cap_tiles <= 0 || !q || !k_live || !v_live || !k_table || !v_table ||
+        !tile_src || !pair_src || !pair_info || !totals || !o)
+        return LVQ_EINVAL;
+    if (nq == 0) return LVQ_OK;
+    const int64_t nkv64 = (int64_t)n_tiles * KVB;
+    if (nkv64 > 0x7fffffff) return LVQ_EUNSUPPORTED;
+    const int nkv = (int)nkv64;
+    if (dh != 64 || (ldq & 7) || (ldkv & 7) || ldkv <= 0 || ldkv > 0x7fffffff || (q_hstride & 7) || (kv_hstride & 7) || (q_bstride & 7) || (ldo & 3) ||
+        (o_hstride & 3) || (o_bstride & 3))
+        return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)q | (uintptr_t)q_lo | (uintptr_t)k_live | (uintptr_t)v_live | (uintptr_t)k_table | (uintptr_t)v_table | (uintptr_t)totals) & 15)
+        return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)o | (uintptr_t)o_lo) & 7) return LVQ_EUNSUPPORTED;
+    if (n_heads > 65535 || batch > 65535) return LVQ_EUNSUPPORTED;
+    const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, false, true);
+    if (!pl.k32) return LVQ_EUNSUPPORTED;
+    AttnArgs a{};
+    a.q = q; a.ql = q_lo; a.k = k_live; a.v = v_live;
+    a.B = batch; a.H = n_heads; a.Hkv = n_heads; a.Nq = nq; a.Nkv = nkv; a.dh = dh;
+    a.q_bs = q_bstride; a.ldq = ldq; a.q_hs = q_hstride; a.ldk = ldkv; a.k_hs = kv_hstride; a.ldv = ldkv; a.v_hs = kv_hstride;
+    a.o_bs = o_bstride; a.ldo = ldo; a.o_hs = o_hstride; a.scale = scale; a.o = o; a.ol = o_lo;
+    a.tile_src = tile_src; a.k_tab = k_table; a.v_tab = v_table;
+    a.pair_src = pair_src; a.pair_info = pair_info; a.pair_cap = pair_cap_tiles; a.totals = totals;
+    a.nsplit = pl.nsplit; a.nqt = pl.nqt; a.force_part = 1;
+    LvqArena arena(ws, ws_bytes);
+    a.part = arena.take<float>((size_t)batch * n_heads * pl.nsplit * nq * (dh + 2));
+    int32_t *flags = arena.take<int32_t>((size_t)batch * n_heads);
+    if (!arena.ok) return LVQ_EWORKSPACE;
+    hipStream_t st = lvq_s(stream);
+    const size_t lds = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16 + 2 * 256 * sizeof(int32_t);     // ring + redo flag + source windows
+    const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
+    const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;
+    if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
+    const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
+    if (hipMemsetAsync(flags, 0, (size_t)batch * n_heads * sizeof(int32_t), st) != hipSuccess) return LVQ_ELAUNCH;
+    a.flags = flags;
+    launch_k32<2>(a, pl.k32, q_lo != nullptr, nwg, lds, st);
+    hipLaunchKernelGGL(k_attn_combine_signed, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
+    // predicated full re-run of the flagged (batch, head) pairs: every workgroup of an unflagged pair returns at once
+    a.flags = nullptr; a.pred = flags; a.pair_src = nullptr; a.pair_info = nullptr; a.totals = nullptr;
+    launch_k32<1>(a, pl.k32, q_lo != nullptr, nwg, lds, st);
+    hipLaunchKernelGGL(k_attn_combine_signed, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
     return lvq_launch_status();
 }
 
@@ -1250,7 +1458,7 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
     if (((int64_t)nkv * ldk + dh) * 2 >= (1ll << 32) || ((int64_t)nkv * ldv + dh) * 2 >= (1ll << 32)) return LVQ_EUNSUPPORTED;
     hipStream_t st = lvq_s(stream);
     if (dh <= 128 && (dh & 15) == 0) {
-        AttnArgs a;
+        AttnArgs a{};
         a.q = q; a.ql = q_lo; a.k = k; a.kl = k_lo; a.v = v; a.vl = v_lo; a.bias = bias;
         a.B = batch; a.H = n_heads; a.Hkv = n_kv_heads; a.Nq = nq; a.Nkv = nkv; a.dh = dh;
         a.q_bs = q_bstride; a.ldq = ldq; a.q_hs = q_hstride; a.k_bs = k_bstride; a.ldk = ldk; a.k_hs = k_hstride;

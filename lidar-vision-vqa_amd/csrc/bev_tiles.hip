@@ -131,6 +131,63 @@ __global__ void __launch_bounds__(256) k_piece_compact(const int32_t *__restrict
     if ((int)blockIdx.x == nblocks - 1 && tid == 0) { counts[0] = base; counts[1] = base * PCELLS; }
 }
 
+// ---- pass 3 (optional): the per-scene PAIR list of lvq_attention_bf16_tiled_signed.  One workgroup per scene compacts the live
+// pieces of piece_src in stream order; pair tile j of scene s holds live pieces 4 j .. 4 j + 3 twice:
+//   pair_src[(s * cap + j) * 8 + u]     = the piece's first row among the live rows            (u = 0..3: keys 0..31 of the tile)
+//   pair_src[(s * cap + j) * 8 + 4 + u] = ~(its first row in the table) = ~(8 e), e = t * 8 + p (keys 32..63: subtracted)
+// The last tile is padded with table piece 0 in BOTH halves (+c - c).  pair_info[2 s] = pair tiles (or 0), pair_info[2 s + 1] = 1
+// when the signed stream is shorter than the scene's full stream of nt tiles (and fits cap), else 0 = use the full stream.
+constexpr int PAIR_NT = 1024;
+__global__ void __launch_bounds__(PAIR_NT) k_scene_pairs(const int32_t *__restrict__ piece_src, int nt, int cap, int32_t *__restrict__ pair_src,
+                                                         int32_t *__restrict__ pair_info) {
+    __shared__ int wsum[PAIR_NT / 64];
+    __shared__ int l_run;
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ne = nt * NPIECE;                                  // entries of this scene (multiple of 4: NPIECE = 8)
+    const int32_t *src = piece_src + (int64_t)s * ne;
+    int32_t *dst = pair_src + (int64_t)s * cap * 8;
+    const int cap_p = cap * 4;                                   // live pieces the list can hold
+    if (tid == 0) l_run = 0;
+    __syncthreads();
+    for (int e0 = 0; e0 < ne; e0 += PAIR_NT * 4) {
+        const int e = e0 + tid * 4;
+        int4 v = make_int4(-1, -1, -1, -1);
+        if (e < ne) v = *reinterpret_cast<const int4 *>(src + e);
+        const int f0 = v.x >= 0, f1 = v.y >= 0, f2 = v.z >= 0, f3 = v.w >= 0;
+        const int c = f0 + f1 + f2 + f3;
+        int inc = c;                                             // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(inc, o); if (lane >= o) inc += n; }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        int wb = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < PAIR_NT / 64; ++q) { if (q < wid) wb += wsum[q]; tot += wsum[q]; }
+        int j = l_run + wb + inc - c;
+        const int32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (vv[u] >= 0) {
+                if (j < cap_p) {
+                    dst[(j >> 2) * 8 + (j & 3)] = vv[u];
+                    dst[(j >> 2) * 8 + 4 + (j & 3)] = ~((e + u) * PCELLS);
+                }
+                ++j;
+            }
+        __syncthreads();
+        if (tid == 0) l_run += tot;
+        __syncthreads();
+    }
+    const int n_live = l_run, n_pt = (n_live + 3) >> 2;
+    const bool use = n_pt < nt && n_pt <= cap;
+    if (use && tid < 4 && n_live + tid < n_pt * 4) {             // padding of the last pair tile
+        const int j = n_live + tid;
+        dst[(j >> 2) * 8 + (j & 3)] = ~0;
+        dst[(j >> 2) * 8 + 4 + (j & 3)] = ~0;
+    }
+    if (tid == 0) { pair_info[2 * s] = use ? n_pt : 0; pair_info[2 * s + 1] = use ? 1 : 0; }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // fused token kernel.  512 threads = 8 waves; persistent over the live list.  A work item ("group") = 8 consecutive live pieces =
 // 64 rows = four 16-row MFMA groups; its pieces may belong to different tiles / scenes, each brings its own 4 x 6 halo.
@@ -473,6 +530,15 @@ template <int J> static int launch_tile_tokens(const bt::TokArgs &a, bool x3, bo
     if (x3 && olo) hipLaunchKernelGGL((bt::k_tile_tokens<J, true, true>), dim3((unsigned)grid), dim3(512), lds, st, a);
     else if (x3)   hipLaunchKernelGGL((bt::k_tile_tokens<J, true, false>), dim3((unsigned)grid), dim3(512), lds, st, a);
     else           hipLaunchKernelGGL((bt::k_tile_tokens<J, false, false>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    return lvq_launch_status();
+}
+
+// Per-scene pair list for lvq_attention_bf16_tiled_signed (see k_scene_pairs): pair_src [batch, cap_tiles, 8], pair_info [batch, 2].
+extern "C" int lvq_bev_scene_pairs(const int32_t *piece_src, int batch, int n_tiles, int cap_tiles, int32_t *pair_src, int32_t *pair_info,
+                                   lvq_stream_t stream) {
+    if (!piece_src || !pair_src || !pair_info || batch <= 0 || n_tiles <= 0 || cap_tiles <= 0) return LVQ_EINVAL;
+    if (((uintptr_t)piece_src & 15) || (int64_t)n_tiles * bt::NPIECE * bt::PCELLS > 0x7fffffff || batch > 65535) return LVQ_EUNSUPPORTED;
+    hipLaunchKernelGGL(bt::k_scene_pairs, dim3(batch), dim3(bt::PAIR_NT), 0, lvq_s(stream), piece_src, n_tiles, cap_tiles, pair_src, pair_info);
     return lvq_launch_status();
 }
 

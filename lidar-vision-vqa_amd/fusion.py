@@ -151,6 +151,31 @@ class VATBlock(_HipModule):
         y, _ = ops.linear(o, self._w(self.ca.out_proj.weight), self.ca.out_proj.bias, residual=q2, out_f32=True, tag="ca_out_proj")
         return y
 
+    # ---- first block of VATLiDAR: the query side does not depend on the scene (vat_lidar.py:259-270 -> vat_blocks.py:37-42) ----
+    def shared_query_side(self, q1: torch.Tensor, nq: int) -> Tuple[torch.Tensor, BF]:
+        """q1 [nq, d] fp32 (ONE copy of the learned queries) -> (q after self-attention [nq, d] fp32, Q projection of the
+        cross-attention BF [nq, d]): computed once per step instead of once per scene."""
+        d = self.d_model
+        q2 = self._self_attn(q1, 1, nq)
+        _, qn = ops.layernorm(q2, self.ca_ln.weight, self.ca_ln.bias, self.ca_ln.eps, self._split())
+        _, qp = ops.linear(qn, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(0, d), tag="ca_q_proj")
+        return q2, qp
+
+    def forward_tokens_tiled_signed(self, q2_1: torch.Tensor, qp: BF, totals: torch.Tensor, x_live: BF, kv_table: torch.Tensor,
+                                    tile_src: torch.Tensor, rows_dev: torch.Tensor, B: int, nq: int, n_tiles: int) -> torch.Tensor:
+        """forward_tokens_tiled for scene-independent queries: the attention streams each scene's LIVE pieces only (twice: live rows
+        added, the table rows at their positions subtracted from the per-model `totals`), csrc/attention.hip `signed pair stream`."""
+        d, h = self.d_model, self.n_heads
+        dh = d // h
+        kv_live, _ = ops.linear_live_rows(x_live, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, rows_dev, (d, 3 * d), tag="ca_kv_proj")
+        pair_src, pair_info = ops.bev_scene_pairs(tile_src, B, n_tiles)
+        o = ops.attention_tiled_signed(qp, kv_live, kv_table, tile_src, pair_src, pair_info, totals, batch=B, n_heads=h, nq=nq, n_tiles=n_tiles,
+                                       dh=dh, scale=1.0 / math.sqrt(dh), shared_q=True, tag="ca_attn")
+        q2 = q2_1.unsqueeze(0).expand(B, nq, d).reshape(B * nq, d)
+        y, _ = ops.linear(o, self._w(self.ca.out_proj.weight), self.ca.out_proj.bias, residual=q2, out_f32=True, tag="ca_out_proj")
+        self._last_pair_info = pair_info                      # device tensor, read by bench / tests only
+        return self._mlp(y)
+
     def forward_tokens_tiled(self, q2, x_live, kv_table, tile_src, rows_dev, B, nq, n_tiles) -> torch.Tensor:
         q2 = self._self_attn(q2, B, nq)
         q2 = self._cross_attn_tiled(q2, x_live, kv_table, tile_src, rows_dev, B, nq, n_tiles)
@@ -346,6 +371,22 @@ class VATLiDAR(_HipModule):
         self._pe_cache[key] = (ver, tables)
         return tables
 
+    def _signed_totals(self, blk: "VATBlock", qp: BF, table: torch.Tensor, H: int, W: int, dev) -> torch.Tensor:
+        """Softmax sums of block 0's (scene-independent) cross-attention queries over ALL keys of the K|V table -> fp32
+        [heads, nq, 66]; input-independent like the table itself, cached per weights version.  `qp` is this step's Q projection:
+        the cached totals belong to exactly these bits as long as the version key is unchanged."""
+        params = [self.query, self.view_embed, blk.sa_ln.weight, blk.sa_ln.bias, blk.sa.in_proj_weight, blk.sa.in_proj_bias, blk.sa.out_proj.weight,
+                  blk.sa.out_proj.bias, blk.ca_ln.weight, blk.ca_ln.bias, blk.ca.in_proj_weight, blk.ca.in_proj_bias]
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(), table.data_ptr())
+        key = ("signed_totals", H, W, dev)
+        hit = self._pe_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        dh = blk.d_model // blk.n_heads
+        tot = ops.attention_stream_totals(qp, table, n_heads=blk.n_heads, nq=self.n_queries, nkv=H * W, dh=dh, scale=1.0 / math.sqrt(dh))
+        self._pe_cache[key] = (ver, tot)
+        return tot
+
     def forward_pillars(self, pillar_features: torch.Tensor, coords_bzyx: torch.Tensor, n_live: Optional[torch.Tensor],
                         batch: int, H: int, W: int, all_tiles_live: bool = False) -> torch.Tensor:
         """Same result as forward(PointPillarScatter(pillars)) without the dense BEV canvas.  Default route (shapes of
@@ -365,10 +406,17 @@ class VATLiDAR(_HipModule):
         idx = ops.pillar_index_map(coords_bzyx, n_live, batch, H, W)
         live, src, counts = ops.bev_tiles(idx, batch, H, W, dev, force_all=all_tiles_live)
         x_live = self._tile_tokens(feat, idx, live, counts, batch * nt * 64, batch, H, W)
-        q2 = self._queries(batch)
-        for blk, table in zip(self.blocks, tables):
+        signed = not all_tiles_live and not os.environ.get("LVQ_NO_SIGNED_STREAM")
+        q2 = None if signed else self._queries(batch)
+        for li, (blk, table) in enumerate(zip(self.blocks, tables)):
             blk.precision = self.precision
-            q2 = blk.forward_tokens_tiled(q2, x_live, table, src, counts[1:], batch, self.n_queries, nt)
+            if li == 0 and signed:
+                # block 0: the queries are the same for every scene -> query side once, attention over the live pieces only
+                q2_1, qp = blk.shared_query_side(self._queries(1), self.n_queries)
+                totals = self._signed_totals(blk, qp, table, H, W, dev)
+                q2 = blk.forward_tokens_tiled_signed(q2_1, qp, totals, x_live, table, src, counts[1:], batch, self.n_queries, nt)
+            else:
+                q2 = blk.forward_tokens_tiled(q2, x_live, table, src, counts[1:], batch, self.n_queries, nt)
         self._last_tile_counts = counts                       # device tensor (live tiles, live rows): read by bench / tests only
         return _post_head(self, q2, self.final_ln, self.post).view(batch, self.n_queries, self.d_model)
 

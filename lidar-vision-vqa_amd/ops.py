@@ -305,6 +305,69 @@ def attention_tiled(q: BF, kv_live: torch.Tensor, kv_table: torch.Tensor, tile_s
     return oh, ol
 
 
+def _att_ws(dev, nbytes: int) -> torch.Tensor:
+    key = (dev.index, "attn")
+    ws = _ATT_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _ATT_WS[key] = ws
+    return ws
+
+
+def attention_stream_totals(q: BF, kv: torch.Tensor, *, n_heads: int, nq: int, nkv: int, dh: int, scale: float) -> torch.Tensor:
+    """Unnormalised softmax sums (O | m | l) of ONE batch of queries q BF [nq, d] over the dense key stream kv [nkv, 2d] (K | V packed,
+    plain bf16) -> fp32 [n_heads, nq, dh + 2]: the per-model totals of attention_tiled_signed."""
+    qh, ql = q
+    dev = qh.device
+    d = n_heads * dh
+    L = F.lib()
+    nbytes = int(L.lvq_attention_stream_totals_workspace_bytes(F.cint(n_heads), F.cint(nq), F.cint(nkv), F.cint(dh)))
+    if nbytes == 0:
+        raise F.LvqError(f"attention_stream_totals: shape (nq={nq}, nkv={nkv}, dh={dh}) is not a long-stream shape")
+    ws = _att_ws(dev, nbytes)
+    tot = torch.empty((n_heads, nq, dh + 2), dtype=torch.float32, device=dev)
+    rc = L.lvq_attention_bf16_stream_totals(F.ptr(qh), F.ptr(ql), F.ptr(kv), F.ptr(kv[:, d:]), F.cint(n_heads), F.cint(nq), F.cint(nkv), F.cint(dh),
+                                            F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.cfloat(scale), F.ptr(tot), F.ptr(ws), F.csize(ws.numel()),
+                                            F.stream_ptr(dev))
+    F.check(rc, f"lvq_attention_bf16_stream_totals (H={n_heads}, nq={nq}, nkv={nkv})")
+    return tot
+
+
+def bev_scene_pairs(piece_src: torch.Tensor, batch: int, n_tiles: int):
+    """Per-scene pair lists of the signed stream -> (pair_src [batch, n_tiles, 8] i32, pair_info [batch, 2] i32 = pair tiles, use flag)."""
+    dev = piece_src.device
+    pair_src = torch.empty((batch, n_tiles, 8), dtype=torch.int32, device=dev)
+    pair_info = torch.empty((batch, 2), dtype=torch.int32, device=dev)
+    rc = F.lib().lvq_bev_scene_pairs(F.ptr(piece_src), F.cint(batch), F.cint(n_tiles), F.cint(n_tiles), F.ptr(pair_src), F.ptr(pair_info),
+                                     F.stream_ptr(dev))
+    F.check(rc, "lvq_bev_scene_pairs")
+    return pair_src, pair_info
+
+
+def attention_tiled_signed(q: BF, kv_live: torch.Tensor, kv_table: torch.Tensor, tile_src: torch.Tensor, pair_src: torch.Tensor,
+                           pair_info: torch.Tensor, totals: torch.Tensor, *, batch: int, n_heads: int, nq: int, n_tiles: int, dh: int, scale: float,
+                           shared_q: bool, tag: Optional[str] = None) -> BF:
+    """attention_tiled over the live pieces only (queries independent of the batch; `totals` from attention_stream_totals with the
+    SAME q).  q BF [nq, d] when shared_q else [batch*nq, d] (identical per batch) -> BF [batch*nq, d]."""
+    qh, ql = q
+    dev = qh.device
+    d = n_heads * dh
+    oh, ol = _bf_empty((batch * nq, d), dev, ql is not None)
+    L = F.lib()
+    nbytes = int(L.lvq_attention_tiled_signed_workspace_bytes(F.cint(batch), F.cint(n_heads), F.cint(nq), F.cint(n_tiles), F.cint(dh)))
+    if nbytes == 0:
+        raise F.LvqError(f"attention_tiled_signed: shape (nq={nq}, tiles={n_tiles}, dh={dh}) is not a long-stream shape")
+    ws = _att_ws(dev, nbytes)
+    with region(tag, dev):
+        rc = L.lvq_attention_bf16_tiled_signed(F.ptr(qh), F.ptr(ql), F.ptr(kv_live), F.ptr(kv_live[:, d:]), F.ptr(kv_table), F.ptr(kv_table[:, d:]),
+                                               F.ptr(tile_src), F.ptr(pair_src), F.ptr(pair_info), F.cint(pair_src.shape[1]), F.ptr(totals),
+                                               F.cint(batch), F.cint(n_heads), F.cint(nq), F.cint(n_tiles), F.cint(dh),
+                                               F.i64(0 if shared_q else nq * d), F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.i64(nq * d), F.i64(d),
+                                               F.i64(dh), F.cfloat(scale), F.ptr(oh), F.ptr(ol), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
+    F.check(rc, f"lvq_attention_bf16_tiled_signed (B={batch}, H={n_heads}, nq={nq}, tiles={n_tiles})")
+    return oh, ol
+
+
 def scale_add_rows(x: torch.Tensor, add: Optional[torch.Tensor], alpha: float = 1.0) -> torch.Tensor:
     F.require_cuda(x, add)
     rows, d = x.shape

@@ -194,6 +194,107 @@ def test_attention_tiled_equals_dense_on_gathered_rows(B, H, nq, n_tiles, qsplit
         assert torch.equal(got[1], ref[1])
 
 
+def _signed_case(B, H, nq, n_tiles, live_frac, seed, k_live_scale=1.0, k_tab_scale=1.0, v_scale=1.0):
+    """Random tiled stream with ONE copy of the queries: (q BF, live rows, table, piece_src [B, n_tiles, 8]); live fraction per batch."""
+    o = ops()
+    d = H * 64
+    g = torch.Generator().manual_seed(seed)
+    table = torch.randn(n_tiles * 64, 2 * d, generator=g)
+    table[:, :d] *= k_tab_scale
+    table[:, d:] *= v_scale
+    table = table.to(torch.bfloat16).to(DEV)
+    fr = torch.tensor(live_frac if isinstance(live_frac, (list, tuple)) else [live_frac] * B).view(B, 1, 1)
+    is_live = torch.rand(B, n_tiles, 8, generator=g) < fr
+    n_l = int(is_live.sum())
+    live = torch.randn((n_l + 1) * 8, 2 * d, generator=g)
+    live[:, :d] *= k_live_scale
+    live[:, d:] *= v_scale
+    live = live.to(torch.bfloat16).to(DEV)
+    e = torch.arange(n_tiles * 8).view(1, n_tiles, 8)
+    rank = (torch.cumsum(is_live.permute(1, 0, 2).reshape(-1).int(), 0) - 1).view(n_tiles, B, 8).permute(1, 0, 2)     # (tile, scene, piece) order
+    src = torch.where(is_live, 8 * rank, ~(8 * e).expand(B, n_tiles, 8)).to(torch.int32)
+    q = torch.randn(nq, d, generator=g).to(DEV)
+    return o.cast(q, True), live, table, src, is_live
+
+
+def test_scene_pairs_vs_numpy():
+    o = ops()
+    B, nt = 4, 96
+    _, _, _, src, is_live = _signed_case(B, 2, 64, nt, [0.3, 0.0, 0.7, 0.05], 3)
+    pair_src, pair_info = o.bev_scene_pairs(src.to(DEV).contiguous().view(-1), B, nt)
+    ps, pi = pair_src.cpu().numpy(), pair_info.cpu().numpy()
+    s_np = src.numpy()
+    for b in range(B):
+        lv = [(int(s_np[b, t, p]), 8 * (8 * t + p)) for t in range(nt) for p in range(8) if s_np[b, t, p] >= 0]
+        n_pt = (len(lv) + 3) // 4
+        use = n_pt < nt
+        assert pi[b, 1] == int(use) and pi[b, 0] == (n_pt if use else 0)
+        if not use:
+            continue
+        for j, (row, trow) in enumerate(lv):
+            assert ps[b, j // 4, j % 4] == row and ps[b, j // 4, 4 + j % 4] == ~trow
+        for j in range(len(lv), 4 * n_pt):                         # padding: table piece 0 in both halves
+            assert ps[b, j // 4, j % 4] == -1 and ps[b, j // 4, 4 + j % 4] == -1
+
+
+def _full_reference(o, qb, live, table, src, B, H, nq, n_tiles):
+    d = H * 64
+    qh = qb[0].unsqueeze(0).expand(B, nq, d).reshape(B * nq, d).contiguous()
+    ql = qb[1].unsqueeze(0).expand(B, nq, d).reshape(B * nq, d).contiguous()
+    return o.attention_tiled((qh, ql), live, table, src.to(DEV).contiguous().view(-1), batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=64,
+                             scale=1.0 / 8.0)
+
+
+def _signed(o, qb, live, table, src, B, H, nq, n_tiles):
+    srcd = src.to(DEV).contiguous().view(-1)
+    pair_src, pair_info = o.bev_scene_pairs(srcd, B, n_tiles)
+    tot = o.attention_stream_totals(qb, table, n_heads=H, nq=nq, nkv=n_tiles * 64, dh=64, scale=1.0 / 8.0)
+    out = o.attention_tiled_signed(qb, live, table, srcd, pair_src, pair_info, tot, batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=64,
+                                   scale=1.0 / 8.0, shared_q=True)
+    return out, pair_info
+
+
+@pytest.mark.parametrize("B,H,nq,n_tiles,fr", [(3, 2, 120, 64, 0.35), (2, 4, 576, 128, [0.4, 0.9]), (4, 12, 576, 256, [0.0, 0.2, 0.45, 0.6]),
+                                               (1, 2, 120, 67, 0.3)])
+def test_attention_tiled_signed_matches_full_stream(B, H, nq, n_tiles, fr):
+    """TOTALS(table) - table terms at the live positions + live rows == the full stream, up to fp32 accumulation order; batches whose
+    pair list is not shorter (live > 50 %) run their full list inside the same launch."""
+    o = ops()
+    qb, live, table, src, is_live = _signed_case(B, H, nq, n_tiles, fr, 17)
+    ref = _full_reference(o, qb, live, table, src, B, H, nq, n_tiles)
+    (oh, ol), pair_info = _signed(o, qb, live, table, src, B, H, nq, n_tiles)
+    pi = pair_info.cpu().numpy()
+    want_use = [int((int(is_live[b].sum()) + 3) // 4 < n_tiles) for b in range(B)]
+    assert pi[:, 1].tolist() == want_use
+    got, want = o.to_f32((oh, ol)).view(B, nq, -1), o.to_f32(ref).view(B, nq, -1)
+    scale = want.abs().max().item()
+    for b in range(B):                                            # (full-list batches: same stream, the row sum kept in two halves)
+        assert (got[b] - want[b]).abs().max().item() < (2e-5 if want_use[b] else 2e-6) * max(scale, 1.0), (b, (got[b] - want[b]).abs().max().item())
+
+
+@pytest.mark.parametrize("kind", ["cancel", "overflow"])
+def test_attention_tiled_signed_falls_back_when_unusable(kind):
+    """(a) The live keys score far below the table keys they replace: what is left after the subtraction is < 1/16 of the table total
+    -> the (batch, head) is flagged and redone over its full stream (then bit-identical to the full stream).  (b) live scores beyond
+    2^128: the signed sums are not finite -> same re-run (which itself falls back to the classic softmax form)."""
+    o = ops()
+    B, H, nq, n_tiles = 2, 2, 120, 64
+    if kind == "cancel":
+        qb, live, table, src, _ = _signed_case(B, H, nq, n_tiles, [0.45, 0.3], 23, k_live_scale=0.01, k_tab_scale=6.0)
+        # the clean positions must hold almost no mass: shrink their table keys (the live positions keep the large ones)
+        clean = (src < 0).any(0)                                 # [n_tiles, 8]: clean in some batch -> make those table rows small
+        t32 = table.float()
+        rows = clean.view(-1).repeat_interleave(8).to(DEV)
+        t32[rows, :H * 64] *= 0.002
+        table = t32.to(torch.bfloat16)
+    else:
+        qb, live, table, src, _ = _signed_case(B, H, nq, n_tiles, [0.45, 0.3], 23, k_live_scale=400.0)
+    ref = _full_reference(o, qb, live, table, src, B, H, nq, n_tiles)
+    (oh, ol), _ = _signed(o, qb, live, table, src, B, H, nq, n_tiles)
+    assert torch.isfinite(o.to_f32((oh, ol))).all()
+    assert torch.equal(oh, ref[0]) and torch.equal(ol, ref[1])
+
+
 def tiled_cfg(**kw):
     base = dict(n_points=8192, d_model=256, n_heads=4, n_queries=120, n_layers=2, n_patches=196, voxel_pillar=(0.8, 0.8, 8.0), max_pillars=30000)
     base.update(kw)
@@ -211,7 +312,11 @@ def test_tiled_route_is_bit_identical_to_all_tiles_live(prec, monkeypatch):
     off2 = torch.tensor([0, n0, n0, pts.shape[0]], dtype=torch.int32, device=DEV)   # scene 1 is empty
     h, w = cfg.bev_hw
     assert pipe.vat_lidar._tiled_route_ok(64, h, w)
+    signed = pipe(pts, off2, patches)                              # default: block 0 streams the live pieces only (signed pair stream)
+    monkeypatch.setenv("LVQ_NO_SIGNED_STREAM", "1")
     a = pipe(pts, off2, patches)
+    # same operand roundings, different fp32 accumulation order in block 0's attention
+    assert (signed["lidar_tokens"] - a["lidar_tokens"]).abs().max().item() < (2e-2 if prec == "bf16" else 2e-4)
     nl = int(pipe.vat_lidar._last_tile_counts[0])
     assert 0 < nl < 3 * (h // 8) * (w // 8) * 8
     orig = pipe.vat_lidar.forward_pillars
