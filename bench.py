@@ -247,10 +247,10 @@ def main():
     per_step = cfg.n_layers + 1        # launches per step: n_layers (VATLiDAR, the S*HW-key stream) + 1 (fusion block, 196 keys); keep the big ones
     big = lambda tag: [p for i, p in enumerate(events.get(tag, [])) if (i % per_step) < cfg.n_layers]
     kv_ms, at_ms = avg_ms(big("ca_kv_proj")), avg_ms(big("ca_attn"))
-    # rows the GEMM actually projects: the tiled key stream computes K|V for the LIVE pieces only (clean pieces come from the
-    # per-model table) -> EXECUTED rows, read back once after the timed region; the dense routes project every BEV cell
+    # rows the GEMM actually projects: the tiled key stream computes K|V for the DIRTY cells only (a pillar in the 3 x 3 neighbourhood; clean
+    # cells come from the per-model table) -> EXECUTED rows, read back once after the timed region; the dense routes project every BEV cell
     tc = getattr(pipe.vat_lidar, "_last_tile_counts", None)
-    live_rows = int(tc[1]) if tc is not None else S * h * w
+    live_rows = int(tc[2]) if tc is not None else S * h * w
     kv_rows = (live_rows + 255) // 256 * 256             # whole 256-row tiles run
     kv_flops = 2.0 * kv_rows * (2 * d) * d               # 4 d^2 per projected key
     at_flops = 4.0 * S * cfg.n_queries * (h * w) * d     # QK^T + PV over EVERY key (4 nq nkv d per scene)
@@ -262,7 +262,7 @@ def main():
                 "bf16x3": "A and W hi+lo: 3 MFMA passes (executed FLOPs = 3x algorithmic)"}[prec]
         ex = {"bf16": 1, "mixed": 2, "bf16x3": 3}[prec]
         tr, src = profile_traffic([f"k_gemm_256 M={kv_rows} N={2 * d} K={d} {prec}"])
-        roofline_kv = {"bound": "mfma", "kernel": "k_gemm_256 (256x256 tile, LDS-DMA, A ring 3 / W ring 2; VATLiDAR.ca K|V projection over the live key pieces, "
+        roofline_kv = {"bound": "mfma", "kernel": "k_gemm_256 (256x256 tile, LDS-DMA, A ring 3 / W ring 2; VATLiDAR.ca K|V projection over the dirty BEV cells, "
                        f"M = {kv_rows} of {S * h * w} BEV cells, N=2d, K=d); " + form,
                        "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                        "traffic": tr, "traffic_source": src, "avg_launch_ms": round(kv_ms, 4), "flops_per_launch": kv_flops,
@@ -274,8 +274,8 @@ def main():
         form = {"bf16": "Q, K, P, V plain: 1 MFMA pass", "mixed": "Q hi+lo (2 MFMA passes over QK^T), K, P, V plain: executed FLOPs = 1.5x algorithmic",
                 "bf16x3": "all operands hi+lo: executed FLOPs = 3x algorithmic"}[prec]
         ex = {"bf16": 1.0, "mixed": 1.5, "bf16x3": 3.0}[prec]
-        # keys the launch actually streams: block 0's queries are scene-independent, so a scene streams only its live pieces, twice
-        # (live rows added, the table rows at their positions subtracted from the per-model totals) -- read back after the timed region
+        # keys the launch actually streams: block 0's queries are scene-independent, so a scene streams only its dirty cells, twice
+        # (computed rows added, the table rows of the same cells subtracted from the per-model totals) -- read back after the timed region
         pi = getattr(pipe.vat_lidar.blocks[0], "_last_pair_info", None)
         keys_streamed = S * h * w
         if pi is not None:
@@ -336,6 +336,13 @@ def main():
                                        "mode": args.precision, "achieved": hl[args.precision]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                        "frac": hl[args.precision]["frac_of_bf16_peak"], "flops": hl["flops"], "ms": hl[args.precision]["ms"],
                                        "traffic": tr, "traffic_source": src}
+        # context: the sub-path is five launches over a 32768 x 768 activation -- as built it moves 24 B (bf16) / 36 B (hi + lo modes) per
+        # activation element (fp32 in, bf16 LN out, Q, O, fp32 residual in, fp32 out), i.e. its HBM floor is ABOVE its MFMA floor
+        b_el = 24.0 if args.precision == "bf16" else 36.0
+        hb = b_el * 32768 * 768 + 2.0 * 196 * 768 * 4
+        result["roofline_headline"].update({"hbm_bytes_as_built": hb, "hbm_floor_ms": round(hb / (PEAK_HBM_GBS * 1e9) * 1e3, 4),
+                                            "mfma_floor_ms": round(hl["flops"] / (PEAK_BF16_TFLOPS * 1e12) * 1e3, 4),
+                                            "hbm_frac": round(hb / (hl[args.precision]["ms"] * 1e-3) / (PEAK_HBM_GBS * 1e9), 4)})
         result["cross_attn_32768x196"] = {"flops": hl["flops"], **{m: hl[m] for m in MODES}}
         # ---- HBM-bound side: hard / fused-mean / dynamic voxelisers at cfg-3 ----
         hard, mean, dyn, vscenes = voxel_blocks(dev)

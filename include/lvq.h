@@ -222,23 +222,26 @@ size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, int nkv, in
  * Rows >= *n_voxels_dev (if given) are ignored. */
 int lvq_pillar_index_map(const int32_t *coords_bzyx, int64_t m_cap, const int32_t *n_voxels_dev, int batch, int ny, int nx,
                          int32_t *idx_map, lvq_stream_t stream);
-/* Piece bookkeeping.  ny, nx multiples of 8; nt = (ny/8)(nx/8) tiles of 8 x 8 cells per scene, each made of eight 2 x 4-cell
- * PIECES (piece p: row pair p >> 1, column half p & 1; 8 keys).  A piece is live when its 4 x 6-cell halo holds a pillar.
- *   live_list [batch * nt * 8]   code (t * batch + s) * 8 + p of the k-th live piece, in (tile, scene, piece) order
- *   tile_src  [batch * nt * 8]   per (scene s, tile t, piece p) at (s * nt + t) * 8 + p: 8 k (first row of the piece among the live
- *                                rows) or ~(64 t + 8 p) (its first row in the table) when the piece is clean
- *   counts    [2]                live pieces, live rows (= 8 x)
- * force_all != 0 marks every piece live (table build; dense comparator). */
+/* Piece / row bookkeeping.  ny, nx multiples of 8; nt = (ny/8)(nx/8) tiles of 8 x 8 cells per scene, each made of eight 2 x 4-cell
+ * PIECES (piece p: row pair p >> 1, column half p & 1).  Keys run TILE-MAJOR: cell (y, x) is key 64 t + 8 p + 4 (y & 1) + (x & 3).
+ * A cell is DIRTY when its 3 x 3 neighbourhood holds a pillar (its token depends on the scene); a piece is live when it has a dirty
+ * cell.  The token kernel works on live pieces and stores the dirty cells' rows compactly, in (tile, scene, piece, cell) order.
+ *   live_list   [batch * nt * 8]      code (t * batch + s) * 8 + p of the k-th live piece
+ *   piece_dirty [batch * nt * 8][2]   per live piece k: (number of its first dirty row, its 8-bit dirty mask)
+ *   row_src     [batch * ny * nx]     per (scene s, key e) at s * ny * nx + e: row_base + (dirty-row number) for a dirty cell, e (its row
+ *                                     in the per-model table, which occupies rows 0 .. ny*nx-1 of the same K|V buffer) otherwise
+ *   counts      [3]                   live pieces, rows of the live pieces (8 x), dirty rows
+ * force_all != 0 marks every cell dirty (table build with row_base = 0; dense comparator). */
 size_t lvq_bev_tiles_workspace_bytes(int batch, int ny, int nx);
-int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, int force_all, int32_t *live_list, int32_t *tile_src,
-                  int32_t *counts, void *ws, size_t ws_bytes, lvq_stream_t stream);
-/* Tokens of the live tiles, fused: pillar gather + depthwise 3x3 + GELU (refine, vat_lidar.py:212-221; tap order and fmaf chain of
+int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, int force_all, int row_base, int32_t *live_list, int32_t *piece_dirty,
+                  int32_t *row_src, int32_t *counts, void *ws, size_t ws_bytes, lvq_stream_t stream);
+/* Tokens of the dirty cells, fused: pillar gather + depthwise 3x3 + GELU (refine, vat_lidar.py:212-221; tap order and fmaf chain of
  * lvq_dwconv3x3_gelu) -> 1x1 conv (proj) -> LayerNorm (norm_tokens) -> + positional table (pe_tiled [ny*nx, n] fp32 in tile-major
- * row order).  x [cap_tiles * 64, n] row 64 k + cell = cell (8 y + x inside the tile) of the k-th live tile.  w_lo != NULL: conv
+ * row order).  x [dirty rows, n]: the compact rows numbered by lvq_bev_tiles (capacity cap_tiles * 64).  w_lo != NULL: conv
  * tokens and W as hi + lo (three products); x_lo != NULL additionally stores the lo half of x.  c_in = 64, n in {256, 512, 768,
  * 1024} (else LVQ_EUNSUPPORTED: use lvq_pillar_dwconv3x3_gelu + lvq_gemm_ln_bf16). */
-int lvq_bev_tile_tokens(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *counts,
-                        int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9, const lvq_bf16 *w,
+int lvq_bev_tile_tokens(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *piece_dirty,
+                        const int32_t *counts, int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9, const lvq_bf16 *w,
                         const lvq_bf16 *w_lo, const float *bias, const float *gamma, const float *beta, float eps, const float *pe_tiled,
                         int n, lvq_bf16 *x, lvq_bf16 *x_lo, lvq_stream_t stream);
 /* c[0 .. *m_rows_dev) = a @ w^T + bias over the live rows only (the row count stays on the device); m_cap, n multiples of 256,
@@ -246,24 +249,24 @@ int lvq_bev_tile_tokens(const float *pillar_feat, const int32_t *idx_map, const 
 int lvq_gemm_bf16_live_rows(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,
                             int64_t m_cap, const int32_t *m_rows_dev, int n, int k, int64_t lda, int64_t ldw, int64_t ldc,
                             lvq_bf16 *c_bf16, lvq_bf16 *c_lo, lvq_stream_t stream);
-/* softmax(q K^T * scale) V over the tiled stream: batch b reads the 8 rows of piece p of tile t from row
- * tile_src[(b * n_tiles + t) * 8 + p] of k_live / v_live when that is >= 0, from row ~tile_src of k_table / v_table otherwise.  Shapes of lvq_attention_stream_ok(nq, 64 * n_tiles, 64) only;
- * q plain or hi + lo (mixed mode), K / V plain.  Workspace: lvq_attention_workspace_bytes(batch, n_heads, nq, 64 * n_tiles, 64, 1). */
-int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_live, const lvq_bf16 *v_live,
-                             const lvq_bf16 *k_table, const lvq_bf16 *v_table, const int32_t *tile_src, int batch, int n_heads, int nq,
-                             int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv, int64_t kv_hstride,
-                             int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o, lvq_bf16 *o_lo, void *ws,
-                             size_t ws_bytes, lvq_stream_t stream);
+/* softmax(q K^T * scale) V over the tiled stream: key slot r (0..63) of tile t of batch b is row row_src[(b * n_tiles + t) * 64 + r] of
+ * k_rows / v_rows -- ONE K|V buffer holding the per-model table rows and the computed rows of every batch (lvq_bev_tiles' row_src).
+ * Shapes of lvq_attention_stream_ok(nq, 64 * n_tiles, 64) only; q plain or hi + lo (mixed mode), K / V plain.
+ * Workspace: lvq_attention_workspace_bytes(batch, n_heads, nq, 64 * n_tiles, 64, 1). */
+int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_rows, const lvq_bf16 *v_rows, const int32_t *row_src,
+                             int batch, int n_heads, int nq, int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride,
+                             int64_t ldkv, int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o,
+                             lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream);
 
-/* Attention over the LIVE pieces only, for queries that do not depend on the batch (VATLiDAR's first block, vat_lidar.py:259-270 (q = self.query expanded over the batch + view embedding) and 283-288 (blocks) +
+/* Attention over the DIRTY rows only, for queries that do not depend on the batch (VATLiDAR's first block, vat_lidar.py:259-270 (q = self.query expanded over the batch + view embedding) and 283-288 (blocks) +
  * vat_blocks.py:37-42: learned queries -> self-attention -> ca_ln -> W_q).  With the fixed softmax reference the contribution of a
- * table key to (l, O) is then the same for every batch, so  result = TOTALS(all table keys) - table terms at the batch's live
- * positions + its live rows: a stream over 2 x (live fraction) of the keys.
+ * table key to (l, O) is then the same for every batch, so  result = TOTALS(all table keys) - table terms at the batch's dirty
+ * cells + its computed rows: a stream over 2 x (dirty fraction) of the keys.
  *   lvq_attention_bf16_stream_totals: totals [n_heads, nq, dh + 2] fp32 = unnormalised (O | m | l) of ONE batch of queries over a
  *       dense key stream (the per-model K | V table); once per weights version.
- *   lvq_bev_scene_pairs: pair_src [batch, cap_tiles, 8], pair_info [batch, 2] from lvq_bev_tiles' tile_src -- tile j of a batch holds
- *       its live pieces 4 j .. 4 j + 3 (keys 0..31, added) and the table rows at their positions (keys 32..63, subtracted);
- *       pair_info[2 b] = pair tiles, pair_info[2 b + 1] = 1 when that is shorter than the full stream (else the batch runs tile_src).
+ *   lvq_bev_scene_pairs: pair_src [batch, cap_tiles, 64], pair_info [batch, 2] from lvq_bev_tiles' row_src -- tile j of a batch holds
+ *       its dirty rows 32 j .. 32 j + 31 (keys 0..31, added) and the table rows of the same cells (keys 32..63, subtracted);
+ *       pair_info[2 b] = pair tiles, pair_info[2 b + 1] = 1 when that is shorter than the full stream (else the batch runs row_src).
  *   lvq_attention_bf16_tiled_signed: as lvq_attention_bf16_tiled (same q as the totals; q_bstride = 0 shares one copy).  A
  *       (batch, head) whose signed row sum is not finite or below 1/16 of the table total is redone over its full stream by a
  *       predicated second launch.  Not bit-identical to the full stream (fp32 accumulation order); same operand roundings. */
@@ -271,12 +274,11 @@ size_t lvq_attention_stream_totals_workspace_bytes(int n_heads, int nq, int nkv,
 int lvq_attention_bf16_stream_totals(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k, const lvq_bf16 *v, int n_heads, int nq,
                                      int nkv, int dh, int64_t ldq, int64_t q_hstride, int64_t ldkv, int64_t kv_hstride, float scale,
                                      float *totals, void *ws, size_t ws_bytes, lvq_stream_t stream);
-int lvq_bev_scene_pairs(const int32_t *tile_src, int batch, int n_tiles, int cap_tiles, int32_t *pair_src, int32_t *pair_info,
+int lvq_bev_scene_pairs(const int32_t *row_src, int batch, int n_tiles, int row_base, int cap_tiles, int32_t *pair_src, int32_t *pair_info,
                         lvq_stream_t stream);
 size_t lvq_attention_tiled_signed_workspace_bytes(int batch, int n_heads, int nq, int n_tiles, int dh);
-int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_live, const lvq_bf16 *v_live,
-                                    const lvq_bf16 *k_table, const lvq_bf16 *v_table, const int32_t *tile_src, const int32_t *pair_src,
-                                    const int32_t *pair_info, int pair_cap_tiles, const float *totals, int batch, int n_heads, int nq,
+int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_rows, const lvq_bf16 *v_rows,
+                                    const int32_t *row_src, const int32_t *pair_src, const int32_t *pair_info, int pair_cap_tiles, const float *totals, int batch, int n_heads, int nq,
                                     int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv,
                                     int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o,
                                     lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream);

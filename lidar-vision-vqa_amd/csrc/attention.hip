@@ -37,13 +37,11 @@ struct AttnArgs {
     int nsplit;       // KV splits (flash-decoding style) for few-queries x many-keys shapes
     int nqt;          // query tiles (of 64*QT queries)
     float *part;      // [B*H][nsplit][Nq][dh + 2] fp32 partial (unnormalised O | m | l) when nsplit > 1
-    // tiled key stream (k_attn32 only; bev_tiles.hip): the 8 rows of piece p (0..7) of tile t of batch b start at row
-    // tile_src[(b * ntiles + t) * 8 + p] of k / v when that is >= 0 (live rows, shared by all batches: k_bs / v_bs are not applied)
-    // and at row ~tile_src of k_tab / v_tab otherwise
-    const int32_t *tile_src;
-    const uint16_t *k_tab, *v_tab;
+    // tiled key stream (k_attn32 only; bev_tiles.hip): key slot r (0..63) of tile t of batch b is row row_src[(b * ntiles + t) * 64 + r]
+    // of k / v -- ONE buffer that holds the per-model table rows and the computed rows of every batch (k_bs / v_bs are not applied)
+    const int32_t *row_src;
     // signed pair stream (k_attn32<., ., 2>, lvq_attention_bf16_tiled_signed): batch b with pair_info[2 b + 1] != 0 streams the
-    // pair_info[2 b] tiles of pair_src + b * pair_cap * 8 (bev_tiles.hip: k_scene_pairs) and SUBTRACTS keys 32..63 of every tile; the
+    // pair_info[2 b] tiles of pair_src + b * pair_cap * 64 (bev_tiles.hip: k_scene_pairs) and SUBTRACTS keys 32..63 of every tile; the
     // per-model totals (unnormalised O | m | l per head and query, shared by all batches) are added by the combine kernel
     const int32_t *pair_src, *pair_info;
     int pair_cap;
@@ -596,12 +594,12 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
     float mref = 0.f, lsum = 0.f;
-    float lsum1 = 0.f;                                          // TL == 2: row sum of keys 32..63 of every tile (the subtracted half)
     bool fresh = true;
 
     // TL == 2: this batch's stream is its pair list (signed) or, when that would not be shorter, its full tile list (unsigned)
     const int pair_mode = TL == 2 ? __builtin_amdgcn_readfirstlane(a.pair_info[2 * b + 1]) : 0;
     const uint32_t smask = pair_mode ? 0x80008000u : 0u;        // sign bits of a packed bf16 pair
+    const uint32_t lsign = pair_mode ? 0x80000000u : 0u;
     const int n_tiles = pair_mode ? __builtin_amdgcn_readfirstlane(a.pair_info[2 * b]) : a.Nkv / KVB;
     const int tps = (n_tiles + a.nsplit - 1) / a.nsplit;
     const int t0 = sp * tps;
@@ -613,11 +611,9 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     // Three LDS slots: tile t+2 is requested at the top of tile t into the slot tile t-1 just left; tile t+1 has landed when a
     // counted vmcnt leaves exactly this wave's newest request in flight.
     const int wave_b = __builtin_amdgcn_readfirstlane(b), wave_hk = __builtin_amdgcn_readfirstlane(hk);
-    constexpr bool tiled = TL != 0;                          // the tiled key stream of bev_tiles.hip (a.tile_src etc.)
+    constexpr bool tiled = TL != 0;                          // the tiled key stream of bev_tiles.hip (a.row_src etc.)
     const uint16_t *kbase = a.k + (tiled ? (int64_t)0 : (int64_t)wave_b * a.k_bs) + (int64_t)wave_hk * a.k_hs;
     const uint16_t *vbase = a.v + (tiled ? (int64_t)0 : (int64_t)wave_b * a.v_bs) + (int64_t)wave_hk * a.v_hs;
-    const uint16_t *ktab = tiled ? a.k_tab + (int64_t)wave_hk * a.k_hs : nullptr;
-    const uint16_t *vtab = tiled ? a.v_tab + (int64_t)wave_hk * a.v_hs : nullptr;
     const int r8 = lane >> 3, pch = lane & 7;
     constexpr int NPC = (16 + NW - 1) / NW;                    // DMA pieces per wave per tile (K pieces 0..7, V pieces 8..15)
     // per piece: a loop-invariant 32-bit lane offset; the tile base is a scalar 64-bit add (a per-tile 64-bit multiply per
@@ -630,39 +626,49 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
         doff[j] = (uint32_t)(row * (isv ? a.ldv : a.ldk) + ((pch ^ f) << 3));
     }
     const int64_t kstep = (int64_t)KVB * a.ldk, vstep = (int64_t)KVB * a.ldv;
-    // tiled stream: the piece sources of 32 tiles (256 words) sit in an LDS window, two windows deep, filled by wave 0 with ONE
-    // LDS-DMA each (no registers and no vmcnt wait on a VGPR in a loop that lives on counted vmcnt).  A tile's 8 words are read
-    // into one VGPR (lanes 8 k .. 8 k + 7) right after the previous tile's requests went out, and a piece's row is a v_readlane
-    // and a 32 x 32 -> 64-bit scalar multiply away (K and V share one row stride here).
-    const int32_t *tsrc_b = !tiled ? nullptr : pair_mode ? a.pair_src + (int64_t)wave_b * a.pair_cap * 8 : a.tile_src + (int64_t)wave_b * (a.Nkv / KVB) * 8;
-    int32_t *win = reinterpret_cast<int32_t *>(smem + 3 * TILE_E) + 4;          // [2][256] behind the ring and the redo flag
-    auto win_dma = [&](int w) __attribute__((always_inline)) {                   // wave 0: window w = tiles t0 + 32 w .. + 31
-        const int n_e = n_tiles * 8;
-        int e = (t0 + 32 * w) * 8 + lane * 4;
-        e = e > n_e - 4 ? n_e - 4 : e;                                          // words past the stream's end are never used
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tsrc_b + e),
-                                         (__attribute__((address_space(3))) void *)(win + (w & 1) * 256), 16, 0, 0);
+    // tiled stream: every key slot of a tile has its own source ROW (bev_tiles.hip: a computed row or a row of the per-model table,
+    // both in ONE buffer).  The row words of 8 tiles (512 words) sit in an LDS window, two windows deep, filled by wave 0 with two
+    // LDS-DMAs per window (no registers and no vmcnt wait on a VGPR in a loop that lives on counted vmcnt).  A lane reads the
+    // words of ITS rows (row r8 of each of its pieces; K and V pieces of the same key rows share a word) right after the previous
+    // tile's requests went out; the address is one v_mad_u64_u32 per piece on top of the piece's scalar base.
+    constexpr int WIN_T = 8, WIN_W = WIN_T * KVB;              // tiles / words per window
+    const int32_t *tsrc_b = !tiled ? nullptr : pair_mode ? a.pair_src + (int64_t)wave_b * a.pair_cap * KVB : a.row_src + (int64_t)wave_b * (a.Nkv / KVB) * KVB;
+    int32_t *win = reinterpret_cast<int32_t *>(smem + 3 * TILE_E) + 4;          // [2][512] behind the ring and the redo flag
+    auto win_dma = [&](int w) __attribute__((always_inline)) {                   // wave 0: window w = tiles t0 + 8 w .. + 7
+        const int n_e = n_tiles * KVB;
+#pragma unroll
+        for (int i = 0; i < WIN_W / 256; ++i) {
+            int e = (t0 + WIN_T * w) * KVB + i * 256 + lane * 4;
+            e = e > n_e - 4 ? n_e - 4 : e;                                      // words past the stream's end are never used
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tsrc_b + e),
+                                             (__attribute__((address_space(3))) void *)(win + (w & 1) * WIN_W + i * 256), 16, 0, 0);
+        }
     };
-    auto win_read = [&](int t) __attribute__((always_inline)) -> int {           // the 8 piece sources of tile t, in lanes 8 k .. 8 k + 7
+    constexpr int NRS = NW == 4 ? 2 : NPC;                     // distinct row words per lane and tile (4 waves: pieces w, w + 4 for K and for V)
+    int rs[NRS];                                               // source rows of the tile of the next dma() call
+#pragma unroll
+    for (int j = 0; j < NRS; ++j) rs[j] = 0;
+    auto win_read = [&](int t) __attribute__((always_inline)) {
         const int r = t - t0;
-        return win[((r >> 5) & 1) * 256 + (r & 31) * 8 + (lane & 7)];
+        const int32_t *wp = win + ((r >> 3) & 1) * WIN_W + (r & (WIN_T - 1)) * KVB + r8;
+#pragma unroll
+        for (int j = 0; j < NRS; ++j) rs[j] = wp[((wid + NW * j) & 7) * 8];
     };
-    int ps = 0;                                                                 // sources of the tile of the next dma() call
     const uint32_t ld_t = (uint32_t)a.ldk;                                      // tiled: ldk == ldv < 2^31 (checked by the host)
-    uint32_t dofft[NPC];                                       // tiled form of doff: row r8 of the piece (the piece's first row is the source row)
-    uint64_t lbj[NPC], xtj[NPC];                               // per DMA piece of this wave: the live base (K or V), live ^ table
+    // tiled form of doff: the swizzled chunk only (the row comes from the window).  f(row) of row = 8 piece + r8 depends on the
+    // piece's parity alone, and all pieces of a wave have the parity of wid (NW is even): ONE lane offset for every piece
+    static_assert(NW % 2 == 0, "pieces of a wave share their parity");
+    const int f_t = (((r8 >> 1) & 1) << 2) | ((2 * (wid & 1) + (r8 >> 2)) & 3);
+    const uint32_t dofft = (uint32_t)((pch ^ f_t) << 3);
+    uint64_t lbj[NPC];                                         // per DMA piece of this wave: the K or V base of this head
 #pragma unroll
     for (int j = 0; j < NPC; ++j) {
-        const int pc = wid + NW * j, isv = (pc >> 3) & 1, piece = pc & 7, row = piece * 8 + r8;
-        const int f = (((row >> 1) & 1) << 2) | ((row >> 2) & 3);
-        dofft[j] = (uint32_t)(r8 * ld_t + ((pch ^ f) << 3));
-        const uint64_t lb = reinterpret_cast<uint64_t>(isv ? vbase : kbase), tb = reinterpret_cast<uint64_t>(isv ? vtab : ktab);
-        lbj[j] = lb;
-        xtj[j] = lb ^ tb;
+        const int pc = wid + NW * j, isv = (pc >> 3) & 1;
+        lbj[j] = reinterpret_cast<uint64_t>(isv ? vbase : kbase);
     }
     auto dma = [&](int t, int slot) __attribute__((always_inline)) {
         // tiled: refill the other window once every wave is 4 tiles into the current one (nobody reads the old buffer any more)
-        if (tiled && wid == 0 && ((t - t0) & 31) == 4) win_dma(((t - t0) >> 5) + 1);
+        if (tiled && wid == 0 && ((t - t0) & (WIN_T - 1)) == 4) win_dma(((t - t0) >> 3) + 1);
         const uint16_t *kt = tiled ? nullptr : kbase + t * kstep, *vt = tiled ? nullptr : vbase + t * vstep;   // wave-uniform
 #pragma unroll
         for (int j = 0; j < NPC; ++j) {
@@ -671,11 +677,8 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
                 const int isv = pc >> 3, piece = pc & 7;
                 const uint16_t *src;
                 if (tiled) {
-                    // live or table rows by a bitwise mux, not ?: -- a select between the captured pointers becomes a select between
-                    // ADDRESSES inside the closure, which then stays in scratch memory with every value read back as a vector
-                    const int sr = __builtin_amdgcn_readlane(ps, piece), neg = sr >> 31;
-                    const uint64_t roff = (uint64_t)(uint32_t)(sr ^ neg) * ld_t;                  // row sr, or ~sr of the table
-                    src = reinterpret_cast<const uint16_t *>(lbj[j] ^ (xtj[j] & (uint64_t)(int64_t)neg)) + roff + dofft[j];
+                    const uint32_t row = (uint32_t)rs[NW == 4 ? (j & 1) : j];
+                    src = reinterpret_cast<const uint16_t *>(lbj[j]) + ((uint64_t)row * ld_t + dofft);
                 } else {
                     src = (isv ? vt : kt) + doff[j];
                 }
@@ -684,7 +687,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
                                                  (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
             }
         }
-        if (tiled) ps = win_read(t + 1);                       // in flight until the next call (LDS returns in order)
+        if (tiled) win_read(t + 1);                            // in flight until the next call (LDS returns in order)
     };
     const int my_pieces = (16 - wid + NW - 1) / NW;            // this wave's DMA instructions per tile
 
@@ -796,7 +799,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
                 pk[e] = pack_bf16(x0, x1);
                 if (TL == 2 && kb == 1) pk[e] ^= smask;        // -P for the subtracted half of a pair tile
             }
-            if (TL == 2 && kb == 1) lsum1 += ls; else lsum += ls;
+            lsum += (TL == 2 && kb == 1) ? __uint_as_float(__float_as_uint(ls) ^ lsign) : ls;   // the subtracted half's row sum
             uint4 u0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), u1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             const bf16x8 pf0 = *reinterpret_cast<bf16x8 *>(&u0), pf1 = *reinterpret_cast<bf16x8 *>(&u1);
             lds_tr_wait4(a00, a01, a10, a11);
@@ -842,7 +845,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
             if (wid == 0) win_dma(0);                          // window 1 follows at tile t0 + 4
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            ps = win_read(t0);
+            win_read(t0);
         }
         if (t0 < t1) dma(t0, 0);
         if (t0 + 1 < t1) dma(t0 + 1, 1);
@@ -900,7 +903,6 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     if (tid == 0) *redo_flag = 0;
     stream(std::false_type{});
     fresh = !(t0 < t1);
-    if (TL == 2) lsum = pair_mode ? lsum - lsum1 : lsum + lsum1;
     if (t0 < t1 && !pair_mode) {                                // a signed partial may be anything; the combine kernel judges the total
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
         const float ltot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
@@ -912,7 +914,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
-        lsum = 0.f; lsum1 = 0.f; mref = 0.f; fresh = true;
+        lsum = 0.f; mref = 0.f; fresh = true;
         stream(std::true_type{});
     }
 
@@ -1266,58 +1268,6 @@ extern "C" size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, 
 
 extern "C" int lvq_attention_stream_ok(int nq, int nkv, int dh) { return plan_k32_waves(nq, nkv, dh, false) != 0; }
 
-// VATLiDAR's cross-attention over the TILED key stream of bev_tiles.hip: batch b attends to n_tiles x 64 keys; the 8 rows of piece p
-// of tile t come from row piece_src[(b * n_tiles + t) * 8 + p] of the live K|V rows (>= 0) or from row ~piece_src of the per-model table.  Long-stream kernel only
-// (head_dim 64, n_tiles * 64 >= 4096, lvq_attention_stream_ok(nq, 64 n_tiles, 64)); q plain or hi + lo, K / V plain.
-extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_live, const lvq_bf16 *v_live,
-                                        const lvq_bf16 *k_table, const lvq_bf16 *v_table, const int32_t *tile_src, int batch, int n_heads,
-                                        int nq, int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv,
-                                        int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o,
-                                        lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream) {
-    if (batch <= 0 || n_heads <= 0 || nq < 0 || n_tiles <= 0 || !q || !k_live || !v_live || !k_table || !v_table || !tile_src || !o) return LVQ_EINVAL;
-    if (nq == 0) return LVQ_OK;
-    const int64_t nkv64 = (int64_t)n_tiles * KVB;
-    if (nkv64 > 0x7fffffff) return LVQ_EUNSUPPORTED;
-    const int nkv = (int)nkv64;
-    if (dh != 64 || (ldq & 7) || (ldkv & 7) || ldkv <= 0 || ldkv > 0x7fffffff || (q_hstride & 7) || (kv_hstride & 7) || (q_bstride & 7) || (ldo & 3) || (o_hstride & 3) || (o_bstride & 3))
-        return LVQ_EUNSUPPORTED;
-    if (((uintptr_t)q | (uintptr_t)q_lo | (uintptr_t)k_live | (uintptr_t)v_live | (uintptr_t)k_table | (uintptr_t)v_table) & 15) return LVQ_EUNSUPPORTED;
-    if (((uintptr_t)o | (uintptr_t)o_lo) & 7) return LVQ_EUNSUPPORTED;
-    if (n_heads > 65535 || batch > 65535) return LVQ_EUNSUPPORTED;
-    AttnArgs a{};
-    a.q = q; a.ql = q_lo; a.k = k_live; a.kl = nullptr; a.v = v_live; a.vl = nullptr; a.bias = nullptr;
-    a.B = batch; a.H = n_heads; a.Hkv = n_heads; a.Nq = nq; a.Nkv = nkv; a.dh = dh;
-    a.q_bs = q_bstride; a.ldq = ldq; a.q_hs = q_hstride; a.k_bs = 0; a.ldk = ldkv; a.k_hs = kv_hstride;
-    a.v_bs = 0; a.ldv = ldkv; a.v_hs = kv_hstride; a.o_bs = o_bstride; a.ldo = ldo; a.o_hs = o_hstride;
-    a.scale = scale; a.causal = 0; a.o = o; a.ol = o_lo;
-    a.tile_src = tile_src; a.k_tab = k_table; a.v_tab = v_table;
-    const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, false, true);
-    if (!pl.k32) return LVQ_EUNSUPPORTED;
-    a.nsplit = pl.nsplit; a.nqt = pl.nqt; a.part = nullptr;
-    if (pl.nsplit > 1) {
-        LvqArena arena(ws, ws_bytes);
-        a.part = arena.take<float>((size_t)batch * n_heads * pl.nsplit * nq * (dh + 2));
-        if (!arena.ok) return LVQ_EWORKSPACE;
-    }
-    hipStream_t st = lvq_s(stream);
-    const size_t lds = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16 + 2 * 256 * sizeof(int32_t);     // ring + redo flag + source windows
-    const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
-    const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;
-    if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
-    if (q_lo) {
-        if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 1, 1>), dim3((unsigned)nwg), dim3(384), lds, st, a);
-        else              hipLaunchKernelGGL((k_attn32<4, 1, 1>), dim3((unsigned)nwg), dim3(256), lds, st, a);
-    } else {
-        if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 0, 1>), dim3((unsigned)nwg), dim3(384), lds, st, a);
-        else              hipLaunchKernelGGL((k_attn32<4, 0, 1>), dim3((unsigned)nwg), dim3(256), lds, st, a);
-    }
-    if (a.nsplit > 1) {
-        const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
-        hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
-    }
-    return lvq_launch_status();
-}
-
 namespace {
 template <int TL> void launch_k32(const AttnArgs &a, int nw, bool qs, int64_t nwg, size_t lds, hipStream_t st) {
     if (qs) {
@@ -1328,7 +1278,54 @@ template <int TL> void launch_k32(const AttnArgs &a, int nw, bool qs, int64_t nw
         else         hipLaunchKernelGGL((k_attn32<4, 0, TL>), dim3((unsigned)nwg), dim3(256), lds, st, a);
     }
 }
+constexpr size_t K32_LDS = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16;               // three K+V slots + the redo flag
+constexpr size_t K32_LDS_TILED = K32_LDS + 2 * 8 * KVB * sizeof(int32_t);                  // + two windows of 8 tiles x 64 row words
 }  // namespace
+
+// VATLiDAR's cross-attention over the TILED key stream of bev_tiles.hip: batch b attends to n_tiles x 64 keys; key slot r of tile t is row
+// row_src[(b * n_tiles + t) * 64 + r] of ONE K|V buffer that holds the per-model table rows and the computed rows of every batch.
+// Long-stream kernel only (head_dim 64, n_tiles * 64 >= 4096, lvq_attention_stream_ok(nq, 64 n_tiles, 64)); q plain or hi + lo, K / V plain.
+extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_rows, const lvq_bf16 *v_rows,
+                                        const int32_t *row_src, int batch, int n_heads, int nq, int n_tiles, int dh, int64_t q_bstride, int64_t ldq,
+                                        int64_t q_hstride, int64_t ldkv, int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride,
+                                        float scale, lvq_bf16 *o, lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+    if (batch <= 0 || n_heads <= 0 || nq < 0 || n_tiles <= 0 || !q || !k_rows || !v_rows || !row_src || !o) return LVQ_EINVAL;
+    if (nq == 0) return LVQ_OK;
+    const int64_t nkv64 = (int64_t)n_tiles * KVB;
+    if (nkv64 > 0x7fffffff) return LVQ_EUNSUPPORTED;
+    const int nkv = (int)nkv64;
+    if (dh != 64 || (ldq & 7) || (ldkv & 7) || ldkv <= 0 || ldkv > 0x7fffffff || (q_hstride & 7) || (kv_hstride & 7) || (q_bstride & 7) || (ldo & 3) || (o_hstride & 3) || (o_bstride & 3))
+        return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)q | (uintptr_t)q_lo | (uintptr_t)k_rows | (uintptr_t)v_rows | (uintptr_t)row_src) & 15) return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)o | (uintptr_t)o_lo) & 7) return LVQ_EUNSUPPORTED;
+    if (n_heads > 65535 || batch > 65535) return LVQ_EUNSUPPORTED;
+    AttnArgs a{};
+    a.q = q; a.ql = q_lo; a.k = k_rows; a.kl = nullptr; a.v = v_rows; a.vl = nullptr; a.bias = nullptr;
+    a.B = batch; a.H = n_heads; a.Hkv = n_heads; a.Nq = nq; a.Nkv = nkv; a.dh = dh;
+    a.q_bs = q_bstride; a.ldq = ldq; a.q_hs = q_hstride; a.k_bs = 0; a.ldk = ldkv; a.k_hs = kv_hstride;
+    a.v_bs = 0; a.ldv = ldkv; a.v_hs = kv_hstride; a.o_bs = o_bstride; a.ldo = ldo; a.o_hs = o_hstride;
+    a.scale = scale; a.causal = 0; a.o = o; a.ol = o_lo;
+    a.row_src = row_src;
+    const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, false, true);
+    if (!pl.k32) return LVQ_EUNSUPPORTED;
+    a.nsplit = pl.nsplit; a.nqt = pl.nqt; a.part = nullptr;
+    if (pl.nsplit > 1) {
+        LvqArena arena(ws, ws_bytes);
+        a.part = arena.take<float>((size_t)batch * n_heads * pl.nsplit * nq * (dh + 2));
+        if (!arena.ok) return LVQ_EWORKSPACE;
+    }
+    hipStream_t st = lvq_s(stream);
+    const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
+    const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;
+    if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
+    launch_k32<1>(a, pl.k32, q_lo != nullptr, nwg, K32_LDS_TILED, st);
+    if (a.nsplit > 1) {
+        const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
+        hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
+    }
+    return lvq_launch_status();
+}
+
 
 // ---- the signed pair stream: attention over the LIVE pieces only -------------------------------------------------------------
 // When the queries do not depend on the batch (VATLiDAR's first block: learned queries -> self-attention -> ca_ln -> W_q), the
@@ -1363,7 +1360,7 @@ extern "C" int lvq_attention_bf16_stream_totals(const lvq_bf16 *q, const lvq_bf1
     a.part = arena.take<float>((size_t)n_heads * pl.nsplit * nq * (dh + 2));
     if (!arena.ok) return LVQ_EWORKSPACE;
     hipStream_t st = lvq_s(stream);
-    const size_t lds = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16;
+    const size_t lds = K32_LDS;
     const int64_t ngrp = (int64_t)a.H * a.nsplit;
     launch_k32<0>(a, pl.k32, q_lo != nullptr, (ngrp + 7) / 8 * 8 * a.nqt, lds, st);
     const int64_t total = (int64_t)a.H * a.Nq * (a.dh / 4);
@@ -1381,14 +1378,14 @@ extern "C" size_t lvq_attention_tiled_signed_workspace_bytes(int batch, int n_he
 
 // As lvq_attention_bf16_tiled, with the per-batch pair lists of lvq_bev_scene_pairs and the per-model totals.  The queries must be the
 // ones the totals were computed with (pass q_bstride = 0 to share one copy between the batches).
-extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_live, const lvq_bf16 *v_live,
-                                               const lvq_bf16 *k_table, const lvq_bf16 *v_table, const int32_t *tile_src, const int32_t *pair_src,
+extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_rows, const lvq_bf16 *v_rows,
+                                               const int32_t *row_src, const int32_t *pair_src,
                                                const int32_t *pair_info, int pair_cap_tiles, const float *totals, int batch, int n_heads, int nq,
                                                int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv,
                                                int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o,
                                                lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream) {
-    if (batch <= 0 || n_heads <= 0 || nq < 0 || n_tiles <= 0 || pair_cap_tiles <= 0 || !q || !k_live || !v_live || !k_table || !v_table ||
-        !tile_src || !pair_src || !pair_info || !totals || !o)
+    if (batch <= 0 || n_heads <= 0 || nq < 0 || n_tiles <= 0 || pair_cap_tiles <= 0 || !q || !k_rows || !v_rows || !row_src || !pair_src ||
+        !pair_info || !totals || !o)
         return LVQ_EINVAL;
     if (nq == 0) return LVQ_OK;
     const int64_t nkv64 = (int64_t)n_tiles * KVB;
@@ -1397,18 +1394,18 @@ extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16
     if (dh != 64 || (ldq & 7) || (ldkv & 7) || ldkv <= 0 || ldkv > 0x7fffffff || (q_hstride & 7) || (kv_hstride & 7) || (q_bstride & 7) || (ldo & 3) ||
         (o_hstride & 3) || (o_bstride & 3))
         return LVQ_EUNSUPPORTED;
-    if (((uintptr_t)q | (uintptr_t)q_lo | (uintptr_t)k_live | (uintptr_t)v_live | (uintptr_t)k_table | (uintptr_t)v_table | (uintptr_t)totals) & 15)
+    if (((uintptr_t)q | (uintptr_t)q_lo | (uintptr_t)k_rows | (uintptr_t)v_rows | (uintptr_t)row_src | (uintptr_t)pair_src | (uintptr_t)totals) & 15)
         return LVQ_EUNSUPPORTED;
     if (((uintptr_t)o | (uintptr_t)o_lo) & 7) return LVQ_EUNSUPPORTED;
     if (n_heads > 65535 || batch > 65535) return LVQ_EUNSUPPORTED;
     const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, false, true);
     if (!pl.k32) return LVQ_EUNSUPPORTED;
     AttnArgs a{};
-    a.q = q; a.ql = q_lo; a.k = k_live; a.v = v_live;
+    a.q = q; a.ql = q_lo; a.k = k_rows; a.v = v_rows;
     a.B = batch; a.H = n_heads; a.Hkv = n_heads; a.Nq = nq; a.Nkv = nkv; a.dh = dh;
     a.q_bs = q_bstride; a.ldq = ldq; a.q_hs = q_hstride; a.ldk = ldkv; a.k_hs = kv_hstride; a.ldv = ldkv; a.v_hs = kv_hstride;
     a.o_bs = o_bstride; a.ldo = ldo; a.o_hs = o_hstride; a.scale = scale; a.o = o; a.ol = o_lo;
-    a.tile_src = tile_src; a.k_tab = k_table; a.v_tab = v_table;
+    a.row_src = row_src;
     a.pair_src = pair_src; a.pair_info = pair_info; a.pair_cap = pair_cap_tiles; a.totals = totals;
     a.nsplit = pl.nsplit; a.nqt = pl.nqt; a.force_part = 1;
     LvqArena arena(ws, ws_bytes);
@@ -1416,7 +1413,7 @@ extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16
     int32_t *flags = arena.take<int32_t>((size_t)batch * n_heads);
     if (!arena.ok) return LVQ_EWORKSPACE;
     hipStream_t st = lvq_s(stream);
-    const size_t lds = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16 + 2 * 256 * sizeof(int32_t);     // ring + redo flag + source windows
+    const size_t lds = K32_LDS_TILED;
     const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
     const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;
     if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
@@ -1464,7 +1461,6 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
         a.q_bs = q_bstride; a.ldq = ldq; a.q_hs = q_hstride; a.k_bs = k_bstride; a.ldk = ldk; a.k_hs = k_hstride;
         a.v_bs = v_bstride; a.ldv = ldv; a.v_hs = v_hstride; a.o_bs = o_bstride; a.ldo = ldo; a.o_hs = o_hstride;
         a.scale = scale; a.causal = causal; a.o = o; a.ol = o_lo;
-        a.tile_src = nullptr; a.k_tab = nullptr; a.v_tab = nullptr;
         const int dhp = (dh + 31) / 32 * 32;
         const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, split, bias == nullptr && !causal && (o_lo == nullptr || qsplit));
         if (qsplit && !pl.k32) return LVQ_EUNSUPPORTED;

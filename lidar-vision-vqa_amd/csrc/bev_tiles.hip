@@ -42,9 +42,10 @@ __device__ __forceinline__ void piece_origin(int t, int p, int tw, int &y0, int 
     x0 = (t % tw) * TS + (p & 1) * 4;
 }
 
-// live flag of flat index i = (t * S + s) * 8 + p : any pillar in the 4 x 6 halo (or `force`)
-__device__ __forceinline__ bool piece_live(const int32_t *__restrict__ idx, int64_t i, int S, int H, int W, int force) {
-    if (force) return true;
+// dirty mask of the piece with flat index i = (t * S + s) * 8 + p: bit j = 4 cy + cx is set when cell (cy, cx) of the 2 x 4 piece has a
+// pillar in its 3 x 3 neighbourhood (its token depends on the scene); 0 = the whole piece is clean; `force`: all 8 bits
+__device__ __forceinline__ unsigned piece_mask(const int32_t *__restrict__ idx, int64_t i, int S, int H, int W, int force) {
+    if (force) return 0xffu;
     const int tw = W / TS;
     const int p = (int)(i & 7);
     const int64_t ts = i >> 3;
@@ -52,109 +53,145 @@ __device__ __forceinline__ bool piece_live(const int32_t *__restrict__ idx, int6
     int y0, x0;
     piece_origin(t, p, tw, y0, x0);
     const int32_t *plane = idx + (int64_t)s * H * W;
-    bool live = false;
+    unsigned occ[PH];                                            // occupancy bits of the 4 x 6 halo, one word per row
 #pragma unroll
     for (int r = 0; r < PH; ++r) {
+        occ[r] = 0;
         const int gy = y0 - 1 + r;
         if (gy < 0 || gy >= H) continue;
 #pragma unroll
         for (int c = 0; c < PW; ++c) {
             const int gx = x0 - 1 + c;
-            if (gx >= 0 && gx < W) live = live || plane[(int64_t)gy * W + gx] >= 0;
+            if (gx >= 0 && gx < W && plane[(int64_t)gy * W + gx] >= 0) occ[r] |= 1u << c;
         }
     }
-    return live;
+    unsigned m = 0;
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy) {
+        const unsigned rows = occ[cy] | occ[cy + 1] | occ[cy + 2];
+#pragma unroll
+        for (int cx = 0; cx < 4; ++cx)
+            if (rows & (7u << cx)) m |= 1u << (4 * cy + cx);
+    }
+    return m;
 }
 
-// ---- pass 1: live pieces per block of CNT_BLOCK flat indices ----
+// ---- pass 1: live pieces and dirty rows per block of CNT_BLOCK flat indices: block_cnt[2 b] / [2 b + 1] ----
 __global__ void __launch_bounds__(256) k_piece_count(const int32_t *__restrict__ idx, int S, int H, int W, int force, int64_t total,
                                                      int32_t *__restrict__ block_cnt) {
-    __shared__ int wsum[4];
-    int c = 0;
+    __shared__ int wsum[4][2];
+    int c = 0, dcount = 0;
 #pragma unroll
     for (int u = 0; u < CNT_BLOCK / 256; ++u) {
         const int64_t i = (int64_t)blockIdx.x * CNT_BLOCK + u * 256 + threadIdx.x;
-        if (i < total) c += piece_live(idx, i, S, H, W, force) ? 1 : 0;
+        if (i < total) {
+            const unsigned m = piece_mask(idx, i, S, H, W, force);
+            c += m ? 1 : 0;
+            dcount += __popc(m);
+        }
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    for (int o = 32; o >= 1; o >>= 1) { c += __shfl_xor(c, o); dcount += __shfl_xor(dcount, o); }
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6][0] = c; wsum[threadIdx.x >> 6][1] = dcount; }
     __syncthreads();
-    if (threadIdx.x == 0) block_cnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0) {
+        block_cnt[2 * blockIdx.x] = wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0];
+        block_cnt[2 * blockIdx.x + 1] = wsum[0][1] + wsum[1][1] + wsum[2][1] + wsum[3][1];
+    }
 }
 
-// ---- pass 2: every block re-sums the block counts in front of it (<= a few thousand L2-resident values), recomputes its flags and
+// ---- pass 2: every block re-sums the block counts in front of it (<= a few thousand L2-resident values), recomputes its masks and
 // writes, in (tile, scene, piece) order,
-//   live_list[k]                    = flat index (t * S + s) * 8 + p of the k-th live piece
-//   piece_src[(s * nt + t) * 8 + p] = 8 k (first row of the piece among the live rows) or ~(64 t + 8 p) (its row in the table)
-//   counts[0] = live pieces, counts[1] = live rows (8 x), by the last block
+//   live_list[k]      = flat index (t * S + s) * 8 + p of the k-th live piece
+//   piece_dirty[k]    = (first dirty-row number of the piece, its dirty mask): the piece's dirty cells own consecutive rows of the
+//                       compact row buffer in cell order
+//   row_src[s * HW + 64 t + 8 p + j] = row_base + (dirty-row number) for a dirty cell, 64 t + 8 p + j (its row in the table) otherwise
+//   counts[0] = live pieces, counts[1] = rows of the live pieces (8 x), counts[2] = dirty rows, by the last block
 __global__ void __launch_bounds__(256) k_piece_compact(const int32_t *__restrict__ idx, int S, int H, int W, int force, int64_t total,
-                                                       const int32_t *__restrict__ block_cnt, int nblocks, int32_t *__restrict__ live_list,
-                                                       int32_t *__restrict__ piece_src, int32_t *__restrict__ counts) {
-    __shared__ int wsum[4];
-    __shared__ int l_base;
+                                                       const int32_t *__restrict__ block_cnt, int nblocks, int row_base, int32_t *__restrict__ live_list,
+                                                       int2 *__restrict__ piece_dirty, int32_t *__restrict__ row_src, int32_t *__restrict__ counts) {
+    __shared__ int wsum[4][2];
+    __shared__ int l_base[2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    int c = 0;
-    for (int b = tid; b < (int)blockIdx.x; b += 256) c += block_cnt[b];
+    int c = 0, dcount = 0;
+    for (int b = tid; b < (int)blockIdx.x; b += 256) { c += block_cnt[2 * b]; dcount += block_cnt[2 * b + 1]; }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
-    if (lane == 0) wsum[wid] = c;
+    for (int o = 32; o >= 1; o >>= 1) { c += __shfl_xor(c, o); dcount += __shfl_xor(dcount, o); }
+    if (lane == 0) { wsum[wid][0] = c; wsum[wid][1] = dcount; }
     __syncthreads();
-    if (tid == 0) l_base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0) {
+        l_base[0] = wsum[0][0] + wsum[1][0] + wsum[2][0] + wsum[3][0];
+        l_base[1] = wsum[0][1] + wsum[1][1] + wsum[2][1] + wsum[3][1];
+    }
     __syncthreads();
-    int base = l_base;
+    int base = l_base[0], dbase = l_base[1];
     const int nt = (H / TS) * (W / TS);
+    const int64_t hw = (int64_t)H * W;
     for (int u = 0; u < CNT_BLOCK / 256; ++u) {
         const int64_t i = (int64_t)blockIdx.x * CNT_BLOCK + u * 256 + tid;
-        const bool live = i < total && piece_live(idx, i, S, H, W, force);
-        const unsigned long long m = __ballot(live);
+        const unsigned msk = i < total ? piece_mask(idx, i, S, H, W, force) : 0u;
+        const bool live = msk != 0;
+        const unsigned long long bal = __ballot(live);
+        const int nd = __popc(msk);
+        int inc = nd;                                             // inclusive wave scan of the dirty-row counts
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(inc, o); if (lane >= o) inc += n; }
         __syncthreads();
-        if (lane == 0) wsum[wid] = __popcll(m);
+        if (lane == 63) { wsum[wid][0] = __popcll(bal); wsum[wid][1] = inc; }
         __syncthreads();
-        int wb = 0, tot = 0;
-        for (int q = 0; q < 4; ++q) { if (q < wid) wb += wsum[q]; tot += wsum[q]; }
+        int wb = 0, tot = 0, dwb = 0, dtot = 0;
+        for (int q = 0; q < 4; ++q) { if (q < wid) { wb += wsum[q][0]; dwb += wsum[q][1]; } tot += wsum[q][0]; dtot += wsum[q][1]; }
         if (i < total) {
             const int p = (int)(i & 7);
             const int64_t ts = i >> 3;
             const int t = (int)(ts / S), sc = (int)(ts - (int64_t)t * S);
-            const int64_t o = ((int64_t)sc * nt + t) * NPIECE + p;
+            const int e0 = t * TCELLS + p * PCELLS;               // the piece's first row in the table (tile-major key order)
+            const int d0 = dbase + dwb + inc - nd;               // its first dirty-row number
             if (live) {
-                const int k = base + wb + __popcll(m & ((1ull << lane) - 1ull));
+                const int k = base + wb + __popcll(bal & ((1ull << lane) - 1ull));
                 live_list[k] = (int32_t)i;
-                piece_src[o] = k * PCELLS;
-            } else {
-                piece_src[o] = ~(t * TCELLS + p * PCELLS);
+                piece_dirty[k] = make_int2(d0, (int)msk);
             }
+            int32_t rs[PCELLS];
+#pragma unroll
+            for (int j = 0; j < PCELLS; ++j)
+                rs[j] = (msk >> j) & 1u ? row_base + d0 + __popc(msk & ((1u << j) - 1u)) : e0 + j;
+            int4 *dst = reinterpret_cast<int4 *>(row_src + (int64_t)sc * hw + e0);
+            dst[0] = make_int4(rs[0], rs[1], rs[2], rs[3]);
+            dst[1] = make_int4(rs[4], rs[5], rs[6], rs[7]);
         }
         base += tot;
+        dbase += dtot;
     }
-    if ((int)blockIdx.x == nblocks - 1 && tid == 0) { counts[0] = base; counts[1] = base * PCELLS; }
+    if ((int)blockIdx.x == nblocks - 1 && tid == 0) { counts[0] = base; counts[1] = base * PCELLS; counts[2] = dbase; }
 }
 
-// ---- pass 3 (optional): the per-scene PAIR list of lvq_attention_bf16_tiled_signed.  One workgroup per scene compacts the live
-// pieces of piece_src in stream order; pair tile j of scene s holds live pieces 4 j .. 4 j + 3 twice:
-//   pair_src[(s * cap + j) * 8 + u]     = the piece's first row among the live rows            (u = 0..3: keys 0..31 of the tile)
-//   pair_src[(s * cap + j) * 8 + 4 + u] = ~(its first row in the table) = ~(8 e), e = t * 8 + p (keys 32..63: subtracted)
-// The last tile is padded with table piece 0 in BOTH halves (+c - c).  pair_info[2 s] = pair tiles (or 0), pair_info[2 s + 1] = 1
+// ---- pass 3 (optional): the per-scene PAIR list of lvq_attention_bf16_tiled_signed.  One workgroup per scene compacts the dirty rows of
+// row_src in stream order; pair tile j of scene s holds dirty rows 32 j .. 32 j + 31 twice:
+//   pair_src[(s * cap + j) * 64 + u]      = the computed row (>= row_base)                     (u = 0..31: keys 0..31 of the tile, added)
+//   pair_src[(s * cap + j) * 64 + 32 + u] = the table row of the same cell (its position e)    (keys 32..63: subtracted)
+// The last tile is padded with table row 0 in BOTH halves (+c - c).  pair_info[2 s] = pair tiles (or 0), pair_info[2 s + 1] = 1
 // when the signed stream is shorter than the scene's full stream of nt tiles (and fits cap), else 0 = use the full stream.
 constexpr int PAIR_NT = 1024;
-__global__ void __launch_bounds__(PAIR_NT) k_scene_pairs(const int32_t *__restrict__ piece_src, int nt, int cap, int32_t *__restrict__ pair_src,
+__global__ void __launch_bounds__(PAIR_NT) k_scene_pairs(const int32_t *__restrict__ row_src, int nt, int row_base, int cap, int32_t *__restrict__ pair_src,
                                                          int32_t *__restrict__ pair_info) {
     __shared__ int wsum[PAIR_NT / 64];
     __shared__ int l_run;
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int ne = nt * NPIECE;                                  // entries of this scene (multiple of 4: NPIECE = 8)
-    const int32_t *src = piece_src + (int64_t)s * ne;
-    int32_t *dst = pair_src + (int64_t)s * cap * 8;
-    const int cap_p = cap * 4;                                   // live pieces the list can hold
+    const int ne = nt * TCELLS;                                  // rows of this scene
+    const int32_t *src = row_src + (int64_t)s * ne;
+    int32_t *dst = pair_src + (int64_t)s * cap * TCELLS;
+    const int cap_r = cap * 32;                                  // dirty rows the list can hold
     if (tid == 0) l_run = 0;
     __syncthreads();
     for (int e0 = 0; e0 < ne; e0 += PAIR_NT * 4) {
         const int e = e0 + tid * 4;
-        int4 v = make_int4(-1, -1, -1, -1);
+        int4 v = make_int4(0, 0, 0, 0);
         if (e < ne) v = *reinterpret_cast<const int4 *>(src + e);
-        const int f0 = v.x >= 0, f1 = v.y >= 0, f2 = v.z >= 0, f3 = v.w >= 0;
-        const int c = f0 + f1 + f2 + f3;
+        const int32_t vv[4] = {v.x, v.y, v.z, v.w};
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c += (e < ne && vv[u] >= row_base) ? 1 : 0;
         int inc = c;                                             // inclusive wave scan
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(inc, o); if (lane >= o) inc += n; }
@@ -164,13 +201,12 @@ __global__ void __launch_bounds__(PAIR_NT) k_scene_pairs(const int32_t *__restri
 #pragma unroll
         for (int q = 0; q < PAIR_NT / 64; ++q) { if (q < wid) wb += wsum[q]; tot += wsum[q]; }
         int j = l_run + wb + inc - c;
-        const int32_t vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (vv[u] >= 0) {
-                if (j < cap_p) {
-                    dst[(j >> 2) * 8 + (j & 3)] = vv[u];
-                    dst[(j >> 2) * 8 + 4 + (j & 3)] = ~((e + u) * PCELLS);
+            if (e < ne && vv[u] >= row_base) {
+                if (j < cap_r) {
+                    dst[(j >> 5) * TCELLS + (j & 31)] = vv[u];
+                    dst[(j >> 5) * TCELLS + 32 + (j & 31)] = e + u;
                 }
                 ++j;
             }
@@ -178,12 +214,12 @@ __global__ void __launch_bounds__(PAIR_NT) k_scene_pairs(const int32_t *__restri
         if (tid == 0) l_run += tot;
         __syncthreads();
     }
-    const int n_live = l_run, n_pt = (n_live + 3) >> 2;
+    const int n_dirty = l_run, n_pt = (n_dirty + 31) >> 5;
     const bool use = n_pt < nt && n_pt <= cap;
-    if (use && tid < 4 && n_live + tid < n_pt * 4) {             // padding of the last pair tile
-        const int j = n_live + tid;
-        dst[(j >> 2) * 8 + (j & 3)] = ~0;
-        dst[(j >> 2) * 8 + 4 + (j & 3)] = ~0;
+    if (use && tid < 32 && n_dirty + tid < n_pt * 32) {           // padding of the last pair tile
+        const int j = n_dirty + tid;
+        dst[(j >> 5) * TCELLS + (j & 31)] = 0;
+        dst[(j >> 5) * TCELLS + 32 + (j & 31)] = 0;
     }
     if (tid == 0) { pair_info[2 * s] = use ? n_pt : 0; pair_info[2 * s + 1] = use ? 1 : 0; }
 }
@@ -211,7 +247,8 @@ struct TokArgs {
     const float *bias, *gamma, *beta, *pe;     // [N], [N], [N], positional table [H*W (tile-major), N]
     float eps;
     int S, H, W;
-    uint16_t *xh, *xl;            // [cap rows, N]: row 8 k + (2 x 4 cell index) of live piece k
+    const int2 *piece_dirty;      // per live piece: (first dirty-row number, dirty mask)
+    uint16_t *xh, *xl;            // [dirty rows, N]: the dirty cells of live piece k own rows piece_dirty[k].x .. in cell order
 };
 
 template <int J, bool X3, bool OLO>
@@ -426,13 +463,16 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
         // ---- pass 2: merge the 8 partials (Chan), recompute, normalise, + table, store ----
         {
             const float *pr = part + (buf * NWV * TCELLS) * 2;
-            const int64_t orow0 = g * TCELLS;
 #pragma unroll 1
             for (int gq = 0; gq < 4; ++gq) {
                 const int cell = gq * 16 + l15;
                 const int code = gq == 0 ? code_cur[0] : gq == 1 ? code_cur[1] : gq == 2 ? code_cur[2] : code_cur[3];
-                const bool valid = code >= 0;                       // false past the end of the live list (last group only): no store
-                const int64_t prow = valid ? (int64_t)((code >> 3) / a.S) * TCELLS + (code & 7) * PCELLS + (cell & 7) : 0;
+                const bool in_list = code >= 0;                     // false past the end of the live list (last group only)
+                const int64_t prow = in_list ? (int64_t)((code >> 3) / a.S) * TCELLS + (code & 7) * PCELLS + (cell & 7) : 0;
+                // only DIRTY cells are stored (compact row buffer); a clean cell of a live piece equals its table row bit for bit
+                const int2 pd = in_list ? a.piece_dirty[g * NPIECE + (cell >> 3)] : make_int2(0, 0);
+                const bool valid = (pd.y >> (cell & 7)) & 1;
+                const int64_t orow = pd.x + __popc((unsigned)pd.y & ((1u << (cell & 7)) - 1u));
                 const float *pep = a.pe + prow * N + col0;
                 f32x4 pe0[JH], pe1[JH];                            // requested up front (HBM), consumed per half
 #pragma unroll
@@ -451,8 +491,8 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
                 const float rstd = 1.0f / sqrtf(m2 / (float)N + a.eps);
                 bf16x8 th0, th1, tl0, tl1;
                 load_t(buf, gq, th0, th1, tl0, tl1);
-                uint16_t *dst = a.xh + (orow0 + cell) * N + col0;
-                uint16_t *dl = OLO ? a.xl + (orow0 + cell) * N + col0 : nullptr;
+                uint16_t *dst = a.xh + orow * N + col0;
+                uint16_t *dl = OLO ? a.xl + orow * N + col0 : nullptr;
                 auto half_out = [&](auto hf_tag, const f32x4 (&pe)[JH]) {
                     constexpr int HF = decltype(hf_tag)::value;
                     f32x4 acc[JH];
@@ -499,22 +539,33 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
 extern "C" size_t lvq_bev_tiles_workspace_bytes(int batch, int ny, int nx) {
     if (batch <= 0 || ny <= 0 || nx <= 0) return 0;
     const int64_t total = (int64_t)batch * (ny / 8) * (nx / 8) * bt::NPIECE;
-    return lvq_align((size_t)lvq_cdiv(total, bt::CNT_BLOCK) * sizeof(int32_t)) + 512;      // one live count per counting block
+    return lvq_align((size_t)2 * lvq_cdiv(total, bt::CNT_BLOCK) * sizeof(int32_t)) + 512;      // (live pieces, dirty rows) per counting block
 }
 
-extern "C" int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, int force_all, int32_t *live_list, int32_t *piece_src,
-                             int32_t *counts, void *ws, size_t ws_bytes, lvq_stream_t stream) {
-    if (batch <= 0 || ny <= 0 || nx <= 0 || !live_list || !piece_src || !counts || (!idx_map && !force_all)) return LVQ_EINVAL;
-    if ((ny % 8) || (nx % 8)) return LVQ_EUNSUPPORTED;
-    const int64_t total = (int64_t)batch * (ny / 8) * (nx / 8) * bt::NPIECE;
-    if (total > (1 << 27)) return LVQ_EUNSUPPORTED;                  // flat piece indices and 8 x row offsets stay in int32
-    if (!ws || ws_bytes < lvq_bev_tiles_workspace_bytes(batch, ny, nx)) return LVQ_EWORKSPACE;
-    int32_t *block_cnt = (int32_t *)ws;
-    const int nb = (int)lvq_cdiv(total, bt::CNT_BLOCK);
+extern "C" int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, int force_all, int row_base, int32_t *live_list,
+                             int32_t *piece_dirty, int32_t *row_src, int32_t *counts, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+    if (batch <= 0 || ny <= 0 || nx <= 0 || row_base < 0 || !live_list || !piece_dirty || !row_src || !counts || (!idx_map && !force_all)) return LVQ_EINVAL;
+    if ((ny % bt::TS) || (nx % bt::TS)) return LVQ_EUNSUPPORTED;
+    const int64_t total = (int64_t)batch * (ny / bt::TS) * (nx / bt::TS) * bt::NPIECE;
+    if ((int64_t)row_base + total * bt::PCELLS > 0x7fffffff || batch > 65535) return LVQ_EUNSUPPORTED;      // rows are int32
+    if (((uintptr_t)row_src & 15) || ((uintptr_t)piece_dirty & 7)) return LVQ_EUNSUPPORTED;
+    const int nb = (int)((total + bt::CNT_BLOCK - 1) / bt::CNT_BLOCK);
+    LvqArena arena(ws, ws_bytes);
+    int32_t *block_cnt = arena.take<int32_t>((size_t)2 * nb);
+    if (!arena.ok) return LVQ_EWORKSPACE;
     hipStream_t st = lvq_s(stream);
     hipLaunchKernelGGL(bt::k_piece_count, dim3(nb), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, total, block_cnt);
     hipLaunchKernelGGL(bt::k_piece_compact, dim3(nb), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, total, (const int32_t *)block_cnt, nb,
-                       live_list, piece_src, counts);
+                       row_base, live_list, reinterpret_cast<int2 *>(piece_dirty), row_src, counts);
+    return lvq_launch_status();
+}
+
+// Per-scene pair list for lvq_attention_bf16_tiled_signed (see k_scene_pairs): pair_src [batch, cap_tiles, 64], pair_info [batch, 2].
+extern "C" int lvq_bev_scene_pairs(const int32_t *row_src, int batch, int n_tiles, int row_base, int cap_tiles, int32_t *pair_src,
+                                   int32_t *pair_info, lvq_stream_t stream) {
+    if (!row_src || !pair_src || !pair_info || batch <= 0 || n_tiles <= 0 || cap_tiles <= 0 || row_base < 0) return LVQ_EINVAL;
+    if (((uintptr_t)row_src & 15) || (int64_t)n_tiles * bt::TCELLS > 0x7fffffff || batch > 65535) return LVQ_EUNSUPPORTED;
+    hipLaunchKernelGGL(bt::k_scene_pairs, dim3(batch), dim3(bt::PAIR_NT), 0, lvq_s(stream), row_src, n_tiles, row_base, cap_tiles, pair_src, pair_info);
     return lvq_launch_status();
 }
 
@@ -533,20 +584,11 @@ template <int J> static int launch_tile_tokens(const bt::TokArgs &a, bool x3, bo
     return lvq_launch_status();
 }
 
-// Per-scene pair list for lvq_attention_bf16_tiled_signed (see k_scene_pairs): pair_src [batch, cap_tiles, 8], pair_info [batch, 2].
-extern "C" int lvq_bev_scene_pairs(const int32_t *piece_src, int batch, int n_tiles, int cap_tiles, int32_t *pair_src, int32_t *pair_info,
-                                   lvq_stream_t stream) {
-    if (!piece_src || !pair_src || !pair_info || batch <= 0 || n_tiles <= 0 || cap_tiles <= 0) return LVQ_EINVAL;
-    if (((uintptr_t)piece_src & 15) || (int64_t)n_tiles * bt::NPIECE * bt::PCELLS > 0x7fffffff || batch > 65535) return LVQ_EUNSUPPORTED;
-    hipLaunchKernelGGL(bt::k_scene_pairs, dim3(batch), dim3(bt::PAIR_NT), 0, lvq_s(stream), piece_src, n_tiles, cap_tiles, pair_src, pair_info);
-    return lvq_launch_status();
-}
-
-extern "C" int lvq_bev_tile_tokens(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *counts,
-                                   int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9, const lvq_bf16 *w,
+extern "C" int lvq_bev_tile_tokens(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *piece_dirty,
+                                   const int32_t *counts, int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9, const lvq_bf16 *w,
                                    const lvq_bf16 *w_lo, const float *bias, const float *gamma, const float *beta, float eps, const float *pe_tiled,
                                    int n, lvq_bf16 *x, lvq_bf16 *x_lo, lvq_stream_t stream) {
-    if (batch <= 0 || ny <= 0 || nx <= 0 || cap_tiles <= 0 || !idx_map || !live_list || !counts || !w9 || !w || !gamma || !pe_tiled || !x)
+    if (batch <= 0 || ny <= 0 || nx <= 0 || cap_tiles <= 0 || !idx_map || !live_list || !piece_dirty || !counts || !w9 || !w || !gamma || !pe_tiled || !x)
         return LVQ_EINVAL;
     if (x_lo && !w_lo) return LVQ_EINVAL;
     if (c_in != 64 || (ny % 8) || (nx % 8) || (n % 256) || n < 256 || n > 1024) return LVQ_EUNSUPPORTED;
@@ -554,7 +596,7 @@ extern "C" int lvq_bev_tile_tokens(const float *pillar_feat, const int32_t *idx_
          (uintptr_t)gamma | (uintptr_t)beta) & 15)
         return LVQ_EUNSUPPORTED;
     bt::TokArgs a;
-    a.feat = pillar_feat; a.idx = idx_map; a.live_list = live_list; a.counts = counts; a.w9 = w9; a.b9 = b9; a.wh = w; a.wl = w_lo;
+    a.feat = pillar_feat; a.idx = idx_map; a.live_list = live_list; a.piece_dirty = reinterpret_cast<const int2 *>(piece_dirty); a.counts = counts; a.w9 = w9; a.b9 = b9; a.wh = w; a.wl = w_lo;
     a.bias = bias; a.gamma = gamma; a.beta = beta; a.pe = pe_tiled; a.eps = eps; a.S = batch; a.H = ny; a.W = nx; a.xh = x; a.xl = x_lo;
     hipStream_t st = lvq_s(stream);
     const bool x3 = w_lo != nullptr, olo = x_lo != nullptr;

@@ -1254,7 +1254,8 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
     // 256x256 / two 64-KiB slots: 2/3 of the L2->LDS fill bytes of the 256x128 tile (the bound on these projections);
     // whole tiles only, and enough of them that the coarser grid still fills the 256 CUs several times over
     static LvqLdsOnce once256;      // per device: did the runtime grant 160 KiB of dynamic LDS?
-    if (dma && g.vec_epilogue && m % 256 == 0 && n % 256 == 0 && (m / 256) * (n / 256) * batch >= 1024 &&
+    static const int64_t min256 = getenv("LVQ_GEMM_256X256_MIN_TILES") ? atoll(getenv("LVQ_GEMM_256X256_MIN_TILES")) : 1024;
+    if (dma && g.vec_epilogue && m % 256 == 0 && n % 256 == 0 && (m / 256) * (n / 256) * batch >= min256 &&
         (m / 256) * (n / 256) <= 0x7fffffff && getenv("LVQ_GEMM_NO256X256") == nullptr && getenv("LVQ_GEMM_NO256") == nullptr) {
         const size_t lds = (size_t)5 * 256 * 128;              // A ring 3 x 32 KiB + W ring 2 x 32 KiB
         if (lvq_ensure_lds(once256, {(const void *)k_gemm_256<0, 0>, (const void *)k_gemm_256<1, 0>, (const void *)k_gemm_256<0, 1>,

@@ -136,21 +136,6 @@ class VATBlock(_HipModule):
         y, _ = ops.linear(o, self._w(self.ca.out_proj.weight), self.ca.out_proj.bias, residual=q2, out_f32=True, tag="ca_out_proj")
         return y
 
-    def _cross_attn_tiled(self, q2: torch.Tensor, x_live: BF, kv_table: torch.Tensor, tile_src: torch.Tensor, rows_dev: torch.Tensor,
-                          B: int, nq: int, n_tiles: int) -> torch.Tensor:
-        """Cross-attention over the tiled BEV key stream (csrc/bev_tiles.hip): K|V of the LIVE rows from x_live here, clean tiles
-        from the per-model table.  Plain K / V / P; weights and the query side keep their lo parts in the mixed mode."""
-        d, h = self.d_model, self.n_heads
-        dh = d // h
-        split = self._split()
-        kv_live, _ = ops.linear_live_rows(x_live, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, rows_dev, (d, 3 * d), tag="ca_kv_proj")
-        _, qn = ops.layernorm(q2, self.ca_ln.weight, self.ca_ln.bias, self.ca_ln.eps, split)
-        _, qp = ops.linear(qn, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(0, d), tag="ca_q_proj")
-        o = ops.attention_tiled(qp, kv_live, kv_table, tile_src, batch=B, n_heads=h, nq=nq, n_tiles=n_tiles, dh=dh,
-                                scale=1.0 / math.sqrt(dh), tag="ca_attn")
-        y, _ = ops.linear(o, self._w(self.ca.out_proj.weight), self.ca.out_proj.bias, residual=q2, out_f32=True, tag="ca_out_proj")
-        return y
-
     # ---- first block of VATLiDAR: the query side does not depend on the scene (vat_lidar.py:259-270 -> vat_blocks.py:37-42) ----
     def shared_query_side(self, q1: torch.Tensor, nq: int) -> Tuple[torch.Tensor, BF]:
         """q1 [nq, d] fp32 (ONE copy of the learned queries) -> (q after self-attention [nq, d] fp32, Q projection of the
@@ -161,25 +146,36 @@ class VATBlock(_HipModule):
         _, qp = ops.linear(qn, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(0, d), tag="ca_q_proj")
         return q2, qp
 
-    def forward_tokens_tiled_signed(self, q2_1: torch.Tensor, qp: BF, totals: torch.Tensor, x_live: BF, kv_table: torch.Tensor,
-                                    tile_src: torch.Tensor, rows_dev: torch.Tensor, B: int, nq: int, n_tiles: int) -> torch.Tensor:
-        """forward_tokens_tiled for scene-independent queries: the attention streams each scene's LIVE pieces only (twice: live rows
-        added, the table rows at their positions subtracted from the per-model `totals`), csrc/attention.hip `signed pair stream`."""
+    def forward_tokens_tiled_signed(self, q2_1: torch.Tensor, qp: BF, totals: torch.Tensor, x_rows: BF, kv: torch.Tensor, row_src: torch.Tensor,
+                                    rows_dev: torch.Tensor, B: int, nq: int, n_tiles: int) -> torch.Tensor:
+        """forward_tokens_tiled for scene-independent queries: the attention streams each scene's DIRTY rows only (twice: the computed
+        rows added, the table rows of the same cells subtracted from the per-model `totals`), csrc/attention.hip `signed pair stream`."""
         d, h = self.d_model, self.n_heads
         dh = d // h
-        kv_live, _ = ops.linear_live_rows(x_live, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, rows_dev, (d, 3 * d), tag="ca_kv_proj")
-        pair_src, pair_info = ops.bev_scene_pairs(tile_src, B, n_tiles)
-        o = ops.attention_tiled_signed(qp, kv_live, kv_table, tile_src, pair_src, pair_info, totals, batch=B, n_heads=h, nq=nq, n_tiles=n_tiles,
+        hw = n_tiles * 64
+        ops.linear_live_rows(x_rows, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, rows_dev, (d, 3 * d), tag="ca_kv_proj", out=kv[hw:])
+        pair_src, pair_info = ops.bev_scene_pairs(row_src, B, n_tiles, hw)
+        o = ops.attention_tiled_signed(qp, kv, row_src, pair_src, pair_info, totals, batch=B, n_heads=h, nq=nq, n_tiles=n_tiles,
                                        dh=dh, scale=1.0 / math.sqrt(dh), shared_q=True, tag="ca_attn")
         q2 = q2_1.unsqueeze(0).expand(B, nq, d).reshape(B * nq, d)
         y, _ = ops.linear(o, self._w(self.ca.out_proj.weight), self.ca.out_proj.bias, residual=q2, out_f32=True, tag="ca_out_proj")
         self._last_pair_info = pair_info                      # device tensor, read by bench / tests only
         return self._mlp(y)
 
-    def forward_tokens_tiled(self, q2, x_live, kv_table, tile_src, rows_dev, B, nq, n_tiles) -> torch.Tensor:
+    def forward_tokens_tiled(self, q2: torch.Tensor, x_rows: BF, kv: torch.Tensor, row_src: torch.Tensor, rows_dev: torch.Tensor, B: int, nq: int,
+                             n_tiles: int) -> torch.Tensor:
+        """Block over the tiled BEV key stream (csrc/bev_tiles.hip): K|V of the DIRTY rows from x_rows into kv[HW:], every other key
+        from the per-model table in kv[:HW].  Plain K / V / P; weights and the query side keep their lo parts in the mixed mode."""
+        d, h = self.d_model, self.n_heads
+        dh = d // h
+        hw = n_tiles * 64
         q2 = self._self_attn(q2, B, nq)
-        q2 = self._cross_attn_tiled(q2, x_live, kv_table, tile_src, rows_dev, B, nq, n_tiles)
-        return self._mlp(q2)
+        ops.linear_live_rows(x_rows, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, rows_dev, (d, 3 * d), tag="ca_kv_proj", out=kv[hw:])
+        _, qn = ops.layernorm(q2, self.ca_ln.weight, self.ca_ln.bias, self.ca_ln.eps, self._split())
+        _, qp = ops.linear(qn, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(0, d), tag="ca_q_proj")
+        o = ops.attention_tiled(qp, kv, row_src, batch=B, n_heads=h, nq=nq, n_tiles=n_tiles, dh=dh, scale=1.0 / math.sqrt(dh), tag="ca_attn")
+        y, _ = ops.linear(o, self._w(self.ca.out_proj.weight), self.ca.out_proj.bias, residual=q2, out_f32=True, tag="ca_out_proj")
+        return self._mlp(y)
 
     def _mlp(self, q2: torch.Tensor) -> torch.Tensor:
         split = self._split()
@@ -339,51 +335,61 @@ class VATLiDAR(_HipModule):
         self._pe_cache[("tiled", H, W, dev)] = (pe, pt)
         return pt
 
-    def _tile_tokens(self, feat, idx, live, counts, cap_rows, batch, H, W) -> BF:
+    def _tile_tokens(self, feat, idx, live, dirty, counts, cap_rows, batch, H, W) -> BF:
         C = feat.shape[1]
-        return ops.bev_tile_tokens(feat, idx, live, counts, cap_rows, batch, H, W, self.refine[0].weight.detach().reshape(C, 9).contiguous(),
+        return ops.bev_tile_tokens(feat, idx, live, dirty, counts, cap_rows, batch, H, W, self.refine[0].weight.detach().reshape(C, 9).contiguous(),
                                    self.refine[0].bias, self._w(self.proj.weight), self.proj.bias, self.norm_tokens.weight, self.norm_tokens.bias,
                                    self.norm_tokens.eps, self._pe_tiled(H, W, feat.device), out_lo=False, tag="bev_proj_ln")
 
-    def _kv_tables(self, C: int, H: int, W: int, dev) -> List[torch.Tensor]:
-        """Per layer: K|V rows [H*W, 2d] of the EMPTY scene, by the same kernels that serve the live tiles (every tile forced
-        live), cached per weights version and precision mode -- input-independent like the positional table."""
+    def _kv_buffers(self, C: int, H: int, W: int, dev, batch: int) -> List[torch.Tensor]:
+        """Per layer ONE K|V buffer [HW + batch*HW, 2d] bf16.  Rows 0 .. HW-1: the per-model TABLE = K|V of the EMPTY scene by the same
+        kernels that serve the dirty rows (every cell forced dirty; key order = tile-major), cached per weights version and precision
+        mode -- input-independent like the positional table.  Rows HW ..: the step's computed rows (capacity for `batch` scenes)."""
         params = [self.refine[0].weight, self.refine[0].bias, self.proj.weight, self.proj.bias, self.norm_tokens.weight, self.norm_tokens.bias,
                   self.geo_mlp[0].weight, self.geo_mlp[0].bias, self.geo_mlp[2].weight, self.geo_mlp[2].bias, self.view_embed]
         for blk in self.blocks:
             params += [blk.ca.in_proj_weight, blk.ca.in_proj_bias]
         ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(),)
-        key = ("kv_table", H, W, dev)
+        key = ("kv_buffer", H, W, dev)
+        hw, d = H * W, self.d_model
+        rows = hw + batch * hw
         hit = self._pe_cache.get(key)
         if hit is not None and hit[0] == ver:
-            return hit[1]
-        nt = (H // 8) * (W // 8)
+            if hit[1][0].shape[0] >= rows:
+                return hit[1]
+            bufs = []
+            for old in hit[1]:                                  # a larger batch: new buffers, the table rows copied over
+                buf = torch.empty((rows, 2 * d), dtype=torch.bfloat16, device=dev)
+                buf[:hw].copy_(old[:hw])
+                bufs.append(buf)
+            self._pe_cache[key] = (ver, bufs)
+            return bufs
         idx = torch.full((1, H, W), -1, dtype=torch.int32, device=dev)
-        live, src, counts = ops.bev_tiles(idx, 1, H, W, dev, force_all=True)
+        live, dirty, src, counts = ops.bev_tiles(idx, 1, H, W, dev, 0, force_all=True)
         feat = torch.zeros((1, C), dtype=torch.float32, device=dev)
-        x = self._tile_tokens(feat, idx, live, counts, nt * 64, 1, H, W)
-        d = self.d_model
-        tables = []
+        x = self._tile_tokens(feat, idx, live, dirty, counts, hw, 1, H, W)
+        bufs = []
         for blk in self.blocks:
             blk.precision = self.precision
-            kv, _ = ops.linear_live_rows(x, blk._w(blk.ca.in_proj_weight), blk.ca.in_proj_bias, counts[1:], (d, 3 * d))
-            tables.append(kv)
-        self._pe_cache[key] = (ver, tables)
-        return tables
+            buf = torch.empty((rows, 2 * d), dtype=torch.bfloat16, device=dev)
+            ops.linear_live_rows(x, blk._w(blk.ca.in_proj_weight), blk.ca.in_proj_bias, counts[2:], (d, 3 * d), out=buf[:hw])
+            bufs.append(buf)
+        self._pe_cache[key] = (ver, bufs)
+        return bufs
 
-    def _signed_totals(self, blk: "VATBlock", qp: BF, table: torch.Tensor, H: int, W: int, dev) -> torch.Tensor:
+    def _signed_totals(self, blk: "VATBlock", qp: BF, kv: torch.Tensor, H: int, W: int, dev) -> torch.Tensor:
         """Softmax sums of block 0's (scene-independent) cross-attention queries over ALL keys of the K|V table -> fp32
         [heads, nq, 66]; input-independent like the table itself, cached per weights version.  `qp` is this step's Q projection:
         the cached totals belong to exactly these bits as long as the version key is unchanged."""
         params = [self.query, self.view_embed, blk.sa_ln.weight, blk.sa_ln.bias, blk.sa.in_proj_weight, blk.sa.in_proj_bias, blk.sa.out_proj.weight,
                   blk.sa.out_proj.bias, blk.ca_ln.weight, blk.ca_ln.bias, blk.ca.in_proj_weight, blk.ca.in_proj_bias]
-        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(), table.data_ptr())
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(), kv.data_ptr())
         key = ("signed_totals", H, W, dev)
         hit = self._pe_cache.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
         dh = blk.d_model // blk.n_heads
-        tot = ops.attention_stream_totals(qp, table, n_heads=blk.n_heads, nq=self.n_queries, nkv=H * W, dh=dh, scale=1.0 / math.sqrt(dh))
+        tot = ops.attention_stream_totals(qp, kv[:H * W], n_heads=blk.n_heads, nq=self.n_queries, nkv=H * W, dh=dh, scale=1.0 / math.sqrt(dh))
         self._pe_cache[key] = (ver, tot)
         return tot
 
@@ -402,22 +408,22 @@ class VATLiDAR(_HipModule):
                                           self.refine[0].weight.detach().reshape(C, 9).contiguous(), self.refine[0].bias, self._split())
             return self._decode(self._tokens_to_model(t, H, W, dev), batch, H, W)
         nt = (H // 8) * (W // 8)
-        tables = self._kv_tables(C, H, W, dev)
+        kvs = self._kv_buffers(C, H, W, dev, batch)
         idx = ops.pillar_index_map(coords_bzyx, n_live, batch, H, W)
-        live, src, counts = ops.bev_tiles(idx, batch, H, W, dev, force_all=all_tiles_live)
-        x_live = self._tile_tokens(feat, idx, live, counts, batch * nt * 64, batch, H, W)
+        live, dirty, src, counts = ops.bev_tiles(idx, batch, H, W, dev, H * W, force_all=all_tiles_live)
+        x_live = self._tile_tokens(feat, idx, live, dirty, counts, batch * nt * 64, batch, H, W)
         signed = not all_tiles_live and not os.environ.get("LVQ_NO_SIGNED_STREAM")
         q2 = None if signed else self._queries(batch)
-        for li, (blk, table) in enumerate(zip(self.blocks, tables)):
+        for li, (blk, table) in enumerate(zip(self.blocks, kvs)):
             blk.precision = self.precision
             if li == 0 and signed:
                 # block 0: the queries are the same for every scene -> query side once, attention over the live pieces only
                 q2_1, qp = blk.shared_query_side(self._queries(1), self.n_queries)
                 totals = self._signed_totals(blk, qp, table, H, W, dev)
-                q2 = blk.forward_tokens_tiled_signed(q2_1, qp, totals, x_live, table, src, counts[1:], batch, self.n_queries, nt)
+                q2 = blk.forward_tokens_tiled_signed(q2_1, qp, totals, x_live, table, src, counts[2:], batch, self.n_queries, nt)
             else:
-                q2 = blk.forward_tokens_tiled(q2, x_live, table, src, counts[1:], batch, self.n_queries, nt)
-        self._last_tile_counts = counts                       # device tensor (live tiles, live rows): read by bench / tests only
+                q2 = blk.forward_tokens_tiled(q2, x_live, table, src, counts[2:], batch, self.n_queries, nt)
+        self._last_tile_counts = counts                       # device tensor (live pieces, their rows, dirty rows): read by bench / tests only
         return _post_head(self, q2, self.final_ln, self.post).view(batch, self.n_queries, self.d_model)
 
     def forward(self, bev: torch.Tensor) -> torch.Tensor:

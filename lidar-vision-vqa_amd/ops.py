@@ -227,13 +227,15 @@ def pillar_index_map(coords: torch.Tensor, n_live: Optional[torch.Tensor], batch
 _TILE_WS = {}
 
 
-def bev_tiles(idx: Optional[torch.Tensor], batch: int, ny: int, nx: int, device, force_all: bool = False):
-    """Piece bookkeeping of the tiled key stream (8 x 8-cell tiles of eight 2 x 4-cell pieces) ->
-    (live_list [batch*nt*8] i32, piece_src [batch*nt*8] i32, counts [2] i32 = live pieces, live rows)."""
+def bev_tiles(idx: Optional[torch.Tensor], batch: int, ny: int, nx: int, device, row_base: int, force_all: bool = False):
+    """Piece / row bookkeeping of the tiled key stream (8 x 8-cell tiles of eight 2 x 4-cell pieces; a cell is dirty when its 3 x 3
+    neighbourhood holds a pillar) -> (live_list [batch*nt*8] i32, piece_dirty [batch*nt*8, 2] i32, row_src [batch, ny*nx] i32 absolute rows
+    of the K|V buffer (dirty: row_base + number, clean: table row = key index), counts [3] i32 = live pieces, their rows, dirty rows)."""
     nt = (ny // 8) * (nx // 8)
     live = torch.empty((batch * nt * 8,), dtype=torch.int32, device=device)
-    src = torch.empty((batch * nt * 8,), dtype=torch.int32, device=device)
-    counts = torch.empty((2,), dtype=torch.int32, device=device)
+    dirty = torch.empty((batch * nt * 8, 2), dtype=torch.int32, device=device)
+    src = torch.empty((batch, ny * nx), dtype=torch.int32, device=device)
+    counts = torch.empty((3,), dtype=torch.int32, device=device)
     L = F.lib()
     nbytes = int(L.lvq_bev_tiles_workspace_bytes(F.cint(batch), F.cint(ny), F.cint(nx)))
     key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
@@ -241,21 +243,22 @@ def bev_tiles(idx: Optional[torch.Tensor], batch: int, ny: int, nx: int, device,
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         _TILE_WS[key] = ws
-    rc = L.lvq_bev_tiles(F.ptr(idx), F.cint(batch), F.cint(ny), F.cint(nx), F.cint(1 if force_all else 0), F.ptr(live), F.ptr(src), F.ptr(counts),
-                         F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(device))
+    rc = L.lvq_bev_tiles(F.ptr(idx), F.cint(batch), F.cint(ny), F.cint(nx), F.cint(1 if force_all else 0), F.cint(row_base), F.ptr(live), F.ptr(dirty),
+                         F.ptr(src), F.ptr(counts), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(device))
     F.check(rc, "lvq_bev_tiles")
-    return live, src, counts
+    return live, dirty, src, counts
 
 
-def bev_tile_tokens(feat: torch.Tensor, idx: torch.Tensor, live: torch.Tensor, counts: torch.Tensor, cap_rows: int, batch: int, ny: int, nx: int,
+def bev_tile_tokens(feat: torch.Tensor, idx: torch.Tensor, live: torch.Tensor, dirty: torch.Tensor, counts: torch.Tensor, cap_rows: int, batch: int, ny: int, nx: int,
                     w9: torch.Tensor, b9: Optional[torch.Tensor], w: BF, bias, gamma, beta, eps: float, pe_tiled: torch.Tensor,
                     out_lo: bool, tag: Optional[str] = None) -> BF:
-    """Fused refine conv -> proj -> LayerNorm -> + positional table over the live tiles -> x BF [cap_rows, n]."""
-    F.require_cuda(feat, idx, live, counts, w9, b9, pe_tiled)
+    """Fused refine conv -> proj -> LayerNorm -> + positional table over the live pieces; the DIRTY cells' rows are stored compactly
+    -> x BF [cap_rows, n] (rows 0 .. counts[2]-1 written)."""
+    F.require_cuda(feat, idx, live, dirty, counts, w9, b9, pe_tiled)
     n = w[0].shape[0]
     xh, xl = _bf_empty((cap_rows, n), feat.device, out_lo)
     with region(tag, feat.device):
-        rc = F.lib().lvq_bev_tile_tokens(F.ptr(feat), F.ptr(idx), F.ptr(live), F.ptr(counts), F.i64(batch * (ny // 8) * (nx // 8)), F.cint(batch),
+        rc = F.lib().lvq_bev_tile_tokens(F.ptr(feat), F.ptr(idx), F.ptr(live), F.ptr(dirty), F.ptr(counts), F.i64(batch * (ny // 8) * (nx // 8)), F.cint(batch),
                                          F.cint(ny), F.cint(nx), F.cint(feat.shape[1]), F.ptr(w9), F.ptr(b9), F.ptr(w[0]), F.ptr(w[1]), F.ptr(bias),
                                          F.ptr(gamma), F.ptr(beta), F.cfloat(eps), F.ptr(pe_tiled), F.cint(n), F.ptr(xh), F.ptr(xl),
                                          F.stream_ptr(feat.device))
@@ -263,15 +266,22 @@ def bev_tile_tokens(feat: torch.Tensor, idx: torch.Tensor, live: torch.Tensor, c
     return xh, xl
 
 
-def linear_live_rows(a: BF, w: BF, bias: Optional[torch.Tensor], rows_dev: torch.Tensor, w_rows, tag: Optional[str] = None) -> BF:
-    """a [cap, k] @ w[r0:r1].T + bias over the first *rows_dev rows (device-side count) -> BF [cap, n] (hi only unless a is split)."""
+def linear_live_rows(a: BF, w: BF, bias: Optional[torch.Tensor], rows_dev: torch.Tensor, w_rows, tag: Optional[str] = None,
+                     out: Optional[torch.Tensor] = None) -> BF:
+    """a [cap, k] @ w[r0:r1].T + bias over the first *rows_dev rows (device-side count) -> BF [cap, n] (hi only unless a is split).
+    `out` (plain bf16 [>= cap, n], contiguous): write there instead of a fresh buffer."""
     import ctypes
     ah, al = a
     wh, wl = w
     cap, k = ah.shape
     r0, r1 = w_rows
     n = r1 - r0
-    ch, cl = _bf_empty((cap, n), ah.device, al is not None)
+    if out is not None:
+        if al is not None or out.dtype != torch.bfloat16 or not out.is_contiguous() or out.shape[0] < cap or out.shape[1] != n:
+            raise F.LvqError("linear_live_rows: `out` must be a contiguous plain bf16 [>= cap, n] buffer")
+        ch, cl = out, None
+    else:
+        ch, cl = _bf_empty((cap, n), ah.device, al is not None)
     wo, bo = r0 * k * 2, r0 * 4
     with region(tag, ah.device):
         rc = F.lib().lvq_gemm_bf16_live_rows(F.ptr(ah), F.ptr(al), ctypes.c_void_p(wh.data_ptr() + wo),
@@ -282,25 +292,21 @@ def linear_live_rows(a: BF, w: BF, bias: Optional[torch.Tensor], rows_dev: torch
     return ch, cl
 
 
-def attention_tiled(q: BF, kv_live: torch.Tensor, kv_table: torch.Tensor, tile_src: torch.Tensor, *, batch: int, n_heads: int, nq: int,
-                    n_tiles: int, dh: int, scale: float, tag: Optional[str] = None) -> BF:
-    """q BF [batch*nq, d]; kv_live [cap, 2d] / kv_table [n_tiles*64, 2d] plain bf16 (K | V packed) -> BF [batch*nq, d]."""
+def attention_tiled(q: BF, kv: torch.Tensor, row_src: torch.Tensor, *, batch: int, n_heads: int, nq: int, n_tiles: int, dh: int, scale: float,
+                    tag: Optional[str] = None) -> BF:
+    """q BF [batch*nq, d]; kv [rows, 2d] plain bf16 (K | V packed): the per-model table rows and every batch's computed rows in ONE buffer;
+    row_src [batch, n_tiles*64] i32 = the row of every key slot -> BF [batch*nq, d]."""
     qh, ql = q
     dev = qh.device
     d = n_heads * dh
     oh, ol = _bf_empty((batch * nq, d), dev, ql is not None)
     L = F.lib()
     nbytes = int(L.lvq_attention_workspace_bytes(F.cint(batch), F.cint(n_heads), F.cint(nq), F.cint(n_tiles * 64), F.cint(dh), F.cint(1)))
-    key = (dev.index, "attn")
-    ws = _ATT_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        _ATT_WS[key] = ws
+    ws = _att_ws(dev, nbytes)
     with region(tag, dev):
-        rc = L.lvq_attention_bf16_tiled(F.ptr(qh), F.ptr(ql), F.ptr(kv_live), F.ptr(kv_live[:, d:]), F.ptr(kv_table), F.ptr(kv_table[:, d:]),
-                                        F.ptr(tile_src), F.cint(batch), F.cint(n_heads), F.cint(nq), F.cint(n_tiles), F.cint(dh), F.i64(nq * d),
-                                        F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.i64(nq * d), F.i64(d), F.i64(dh), F.cfloat(scale),
-                                        F.ptr(oh), F.ptr(ol), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
+        rc = L.lvq_attention_bf16_tiled(F.ptr(qh), F.ptr(ql), F.ptr(kv), F.ptr(kv[:, d:]), F.ptr(row_src), F.cint(batch), F.cint(n_heads), F.cint(nq),
+                                        F.cint(n_tiles), F.cint(dh), F.i64(nq * d), F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.i64(nq * d), F.i64(d),
+                                        F.i64(dh), F.cfloat(scale), F.ptr(oh), F.ptr(ol), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
     F.check(rc, f"lvq_attention_bf16_tiled (B={batch}, H={n_heads}, nq={nq}, tiles={n_tiles})")
     return oh, ol
 
@@ -333,22 +339,21 @@ def attention_stream_totals(q: BF, kv: torch.Tensor, *, n_heads: int, nq: int, n
     return tot
 
 
-def bev_scene_pairs(piece_src: torch.Tensor, batch: int, n_tiles: int):
-    """Per-scene pair lists of the signed stream -> (pair_src [batch, n_tiles, 8] i32, pair_info [batch, 2] i32 = pair tiles, use flag)."""
-    dev = piece_src.device
-    pair_src = torch.empty((batch, n_tiles, 8), dtype=torch.int32, device=dev)
+def bev_scene_pairs(row_src: torch.Tensor, batch: int, n_tiles: int, row_base: int):
+    """Per-scene pair lists of the signed stream -> (pair_src [batch, n_tiles, 64] i32, pair_info [batch, 2] i32 = pair tiles, use flag)."""
+    dev = row_src.device
+    pair_src = torch.empty((batch, n_tiles, 64), dtype=torch.int32, device=dev)
     pair_info = torch.empty((batch, 2), dtype=torch.int32, device=dev)
-    rc = F.lib().lvq_bev_scene_pairs(F.ptr(piece_src), F.cint(batch), F.cint(n_tiles), F.cint(n_tiles), F.ptr(pair_src), F.ptr(pair_info),
-                                     F.stream_ptr(dev))
+    rc = F.lib().lvq_bev_scene_pairs(F.ptr(row_src), F.cint(batch), F.cint(n_tiles), F.cint(row_base), F.cint(n_tiles), F.ptr(pair_src),
+                                     F.ptr(pair_info), F.stream_ptr(dev))
     F.check(rc, "lvq_bev_scene_pairs")
     return pair_src, pair_info
 
 
-def attention_tiled_signed(q: BF, kv_live: torch.Tensor, kv_table: torch.Tensor, tile_src: torch.Tensor, pair_src: torch.Tensor,
-                           pair_info: torch.Tensor, totals: torch.Tensor, *, batch: int, n_heads: int, nq: int, n_tiles: int, dh: int, scale: float,
+def attention_tiled_signed(q: BF, kv: torch.Tensor, row_src: torch.Tensor, pair_src: torch.Tensor, pair_info: torch.Tensor, totals: torch.Tensor, *, batch: int, n_heads: int, nq: int, n_tiles: int, dh: int, scale: float,
                            shared_q: bool, tag: Optional[str] = None) -> BF:
-    """attention_tiled over the live pieces only (queries independent of the batch; `totals` from attention_stream_totals with the
-    SAME q).  q BF [nq, d] when shared_q else [batch*nq, d] (identical per batch) -> BF [batch*nq, d]."""
+    """attention_tiled over the dirty rows only (queries independent of the batch; `totals` from attention_stream_totals with the
+    SAME q over the table rows kv[:n_tiles*64]).  q BF [nq, d] when shared_q else [batch*nq, d] (identical per batch) -> BF [batch*nq, d]."""
     qh, ql = q
     dev = qh.device
     d = n_heads * dh
@@ -359,8 +364,7 @@ def attention_tiled_signed(q: BF, kv_live: torch.Tensor, kv_table: torch.Tensor,
         raise F.LvqError(f"attention_tiled_signed: shape (nq={nq}, tiles={n_tiles}, dh={dh}) is not a long-stream shape")
     ws = _att_ws(dev, nbytes)
     with region(tag, dev):
-        rc = L.lvq_attention_bf16_tiled_signed(F.ptr(qh), F.ptr(ql), F.ptr(kv_live), F.ptr(kv_live[:, d:]), F.ptr(kv_table), F.ptr(kv_table[:, d:]),
-                                               F.ptr(tile_src), F.ptr(pair_src), F.ptr(pair_info), F.cint(pair_src.shape[1]), F.ptr(totals),
+        rc = L.lvq_attention_bf16_tiled_signed(F.ptr(qh), F.ptr(ql), F.ptr(kv), F.ptr(kv[:, d:]), F.ptr(row_src), F.ptr(pair_src), F.ptr(pair_info), F.cint(pair_src.shape[1]), F.ptr(totals),
                                                F.cint(batch), F.cint(n_heads), F.cint(nq), F.cint(n_tiles), F.cint(dh),
                                                F.i64(0 if shared_q else nq * d), F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.i64(nq * d), F.i64(d),
                                                F.i64(dh), F.cfloat(scale), F.ptr(oh), F.ptr(ol), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))

@@ -31,6 +31,42 @@ def random_pillars(B, H, W, M, seed, C=64):
     return coords.to(DEV).contiguous(), feat.to(DEV)
 
 
+def _np_bookkeeping(occ, row_base):
+    """numpy restatement of lvq_bev_tiles: occ [B, H, W] bool -> (live codes, piece_dirty, row_src [B, HW], counts)."""
+    B, H, W = occ.shape
+    tw = W // 8
+    nt = (H // 8) * tw
+    pad = np.pad(occ, ((0, 0), (1, 1), (1, 1)))
+    dirty = np.zeros((B, H, W), bool)                                             # a pillar in the 3 x 3 neighbourhood
+    for dy in range(3):
+        for dx in range(3):
+            dirty |= pad[:, dy:dy + H, dx:dx + W]
+    mask = np.zeros((B, nt, 8), np.int64)                                         # bit j = 4 cy + cx of piece p (rows 2 (p >> 1) .., columns 4 (p & 1) ..)
+    for t in range(nt):
+        for p in range(8):
+            y0, x0 = (t // tw) * 8 + (p >> 1) * 2, (t % tw) * 8 + (p & 1) * 4
+            for j in range(8):
+                mask[:, t, p] |= dirty[:, y0 + (j >> 2), x0 + (j & 3)].astype(np.int64) << j
+    codes, pdirty = [], []
+    row_src = np.empty((B, nt * 64), np.int64)
+    nd = 0
+    for t in range(nt):
+        for s in range(B):
+            for p in range(8):
+                m = int(mask[s, t, p])
+                if m:
+                    codes.append((t * B + s) * 8 + p)
+                    pdirty.append((nd, m))
+                for j in range(8):
+                    e = 64 * t + 8 * p + j
+                    if (m >> j) & 1:
+                        row_src[s, e] = row_base + nd
+                        nd += 1
+                    else:
+                        row_src[s, e] = e
+    return codes, pdirty, row_src, (len(codes), 8 * len(codes), nd)
+
+
 @pytest.mark.parametrize("B,H,W,M", [(3, 64, 64, 40), (1, 128, 96, 900), (2, 32, 32, 0), (2, 16, 24, 5000)])
 def test_tile_bookkeeping_vs_numpy(B, H, W, M):
     o = ops()
@@ -42,29 +78,19 @@ def test_tile_bookkeeping_vs_numpy(B, H, W, M):
     c = coords.cpu().numpy()[:M]
     occ[c[:, 0], c[:, 2], c[:, 3]] = True
     assert np.array_equal(idx.cpu().numpy() >= 0, occ)
-    th, tw = H // 8, W // 8
-    nt = th * tw
-    pad = np.pad(occ, ((0, 0), (1, 1), (1, 1)))
-    flags = np.zeros((B, nt, 8), bool)                                            # piece p of tile t: rows 2 (p >> 1) .. +1, columns 4 (p & 1) .. +3
-    for t in range(nt):
-        for p in range(8):
-            y0, x0 = (t // tw) * 8 + (p >> 1) * 2, (t % tw) * 8 + (p & 1) * 4
-            flags[:, t, p] = pad[:, y0:y0 + 4, x0:x0 + 6].any(axis=(1, 2))     # 4 x 6 halo (padded coordinates)
-    live, src, counts = o.bev_tiles(idx, B, H, W, DEV)
-    n = int(counts[0])
-    assert n == int(flags.sum()) and int(counts[1]) == 8 * n
-    order = [(t, s, p) for t in range(nt) for s in range(B) for p in range(8) if flags[s, t, p]]      # (tile, scene, piece) order
-    assert live.cpu().numpy()[:n].tolist() == [(t * B + s) * 8 + p for t, s, p in order]
-    want = np.empty((B, nt, 8), np.int64)
-    for s in range(B):
-        for t in range(nt):
-            for p in range(8):
-                want[s, t, p] = ~(64 * t + 8 * p)
-    for k, (t, s, p) in enumerate(order):
-        want[s, t, p] = 8 * k
-    assert np.array_equal(src.cpu().numpy().reshape(B, nt, 8), want.astype(np.int32))
-    live2, src2, counts2 = o.bev_tiles(idx, B, H, W, DEV, force_all=True)
-    assert int(counts2[0]) == B * nt * 8 and bool((src2 >= 0).all())
+    nt = (H // 8) * (W // 8)
+    base = H * W
+    codes, pdirty, row_src, cnt = _np_bookkeeping(occ, base)
+    live, dirty, src, counts = o.bev_tiles(idx, B, H, W, DEV, base)
+    assert counts.cpu().numpy().tolist() == list(cnt)
+    n = cnt[0]
+    assert live.cpu().numpy()[:n].tolist() == codes
+    assert dirty.cpu().numpy()[:n].tolist() == [list(x) for x in pdirty]
+    assert np.array_equal(src.cpu().numpy(), row_src.astype(np.int32))
+    live2, dirty2, src2, counts2 = o.bev_tiles(idx, B, H, W, DEV, 0, force_all=True)
+    assert counts2.cpu().numpy().tolist() == [B * nt * 8, B * nt * 64, B * nt * 64] and bool((dirty2[:, 1] == 255).all())
+    if B == 1:                                                                    # the table build: every row in key order
+        assert np.array_equal(src2.cpu().numpy()[0], np.arange(H * W))
 
 
 def _tile_major(rows_hw: torch.Tensor, H: int, W: int) -> torch.Tensor:
@@ -98,32 +124,30 @@ def test_tile_tokens_vs_unfused_kernels(n, split):
     idx = o.pillar_index_map(coords, n_live, B, H, W)
     nt = (H // 8) * (W // 8)
     for force in (True, False):
-        live, src, counts = o.bev_tiles(idx, B, H, W, DEV, force_all=force)
-        x = o.bev_tile_tokens(feat, idx, live, counts, B * nt * 64, B, H, W, w9, b9, o.cast(wp, split), bias, gam, bet, 1e-5, pe_t, out_lo=split)
+        live, dirty, src, counts = o.bev_tiles(idx, B, H, W, DEV, 0, force_all=force)
+        x = o.bev_tile_tokens(feat, idx, live, dirty, counts, B * nt * 64, B, H, W, w9, b9, o.cast(wp, split), bias, gam, bet, 1e-5, pe_t, out_lo=split)
         got = o.to_f32(x)
-        nl = int(counts[0])
-        assert nl == B * nt * 8 if force else 0 < nl < B * nt * 8
-        codes = live.cpu().numpy()[:nl]
-        rows = []                                                                 # reference row block of every live piece
-        for cd in codes:
-            p, ts = int(cd) & 7, int(cd) >> 3
-            tt, s = divmod(ts, B)
-            rows.append(ref_t[s, 64 * tt + 8 * p:64 * tt + 8 * p + 8])
-        want = torch.stack(rows).reshape(nl * 8, n)
-        full = got[:nl * 8]
-        assert float((full - want).abs().max()) < (3e-4 if split else 2.0 ** -7 * float(want.abs().max())), force
-    # a clean tile equals the all-empty-scene value of that tile (what the per-model table holds), bit for bit
-    live_e, src_e, counts_e = o.bev_tiles(torch.full_like(idx[:1], -1), 1, H, W, DEV, force_all=True)
-    xe = o.bev_tile_tokens(feat[:1] * 0, torch.full_like(idx[:1], -1), live_e, counts_e, nt * 64, 1, H, W, w9, b9, o.cast(wp, split), bias, gam,
-                           bet, 1e-5, pe_t, out_lo=split)
-    live_f, src_f, counts_f = o.bev_tiles(idx, B, H, W, DEV, force_all=True)
-    xf = o.bev_tile_tokens(feat, idx, live_f, counts_f, B * nt * 64, B, H, W, w9, b9, o.cast(wp, split), bias, gam, bet, 1e-5, pe_t, out_lo=split)
-    srcs = o.bev_tiles(idx, B, H, W, DEV)[1].cpu().numpy().reshape(B, nt, 8)
-    clean = [(s, tt, p) for s in range(B) for tt in range(nt) for p in range(8) if srcs[s, tt, p] < 0][:80]
+        nl, nd = int(counts[0]), int(counts[2])
+        assert (nl == B * nt * 8 and nd == B * nt * 64) if force else (0 < nl < B * nt * 8 and 0 < nd < 8 * nl)
+        srcn = src.cpu().numpy()
+        for s in range(B):                                                        # row row_src[s, e] (when computed) holds key e of scene s
+            e = np.nonzero(srcn[s] != np.arange(H * W))[0] if not force else np.arange(H * W)
+            rows = torch.from_numpy(srcn[s][e].astype(np.int64)).to(DEV)
+            want = ref_t[s][torch.from_numpy(e).to(DEV)]
+            assert float((got[rows] - want).abs().max()) < (3e-4 if split else 2.0 ** -7 * float(want.abs().max())), (force, s)
+    # a clean cell equals the all-empty-scene value of that cell (what the per-model table holds), bit for bit
+    empty = torch.full_like(idx[:1], -1)
+    live_e, dirty_e, src_e, counts_e = o.bev_tiles(empty, 1, H, W, DEV, 0, force_all=True)
+    xe = o.bev_tile_tokens(feat[:1] * 0, empty, live_e, dirty_e, counts_e, nt * 64, 1, H, W, w9, b9, o.cast(wp, split), bias, gam, bet, 1e-5, pe_t,
+                           out_lo=split)
+    live_f, dirty_f, src_f, counts_f = o.bev_tiles(idx, B, H, W, DEV, 0, force_all=True)
+    xf = o.bev_tile_tokens(feat, idx, live_f, dirty_f, counts_f, B * nt * 64, B, H, W, w9, b9, o.cast(wp, split), bias, gam, bet, 1e-5, pe_t, out_lo=split)
+    srcs = o.bev_tiles(idx, B, H, W, DEV, H * W)[2].cpu().numpy()
+    srcf = src_f.cpu().numpy()
+    clean = [(s, e) for s in range(B) for e in range(0, H * W, 7) if srcs[s, e] == e][:200]
     assert clean
-    for s, tt, p in clean:
-        k = (tt * B + s) * 8 + p                                                  # all-live order: entry (tile, scene, piece)
-        assert torch.equal(xf[0][8 * k:8 * k + 8], xe[0][64 * tt + 8 * p:64 * tt + 8 * p + 8])
+    for s, e in clean:
+        assert torch.equal(xf[0][srcf[s, e]], xe[0][e])
 
 
 def test_gemm_live_rows_device_count():
@@ -152,41 +176,39 @@ def test_gemm_live_rows_device_count():
             del canary
 
 
+def _row_case(B, H, n_tiles, dirty_frac, seed, k_new_scale=1.0, k_tab_scale=1.0, shuffle=True):
+    """Random row-granular stream: ONE K|V buffer [table rows (n_tiles*64) | computed rows], row_src [B, n_tiles*64] (key e of batch b is
+    a computed row with probability dirty_frac[b], its table row e otherwise) and the dirty flags."""
+    d = H * 64
+    hw = n_tiles * 64
+    g = torch.Generator().manual_seed(seed)
+    fr = torch.tensor(dirty_frac if isinstance(dirty_frac, (list, tuple)) else [dirty_frac] * B).view(B, 1)
+    is_dirty = torch.rand(B, hw, generator=g) < fr
+    if float(fr[0]) > 0:
+        is_dirty[0, :5] = torch.tensor([True, False, True, True, False])
+    n_d = int(is_dirty.sum())
+    kv = torch.randn(hw + n_d + 7, 2 * d, generator=g)
+    kv[:hw, :d] *= k_tab_scale
+    kv[hw:, :d] *= k_new_scale
+    num = torch.randperm(n_d, generator=g) if shuffle else torch.arange(n_d)         # any numbering of the computed rows is legal
+    src = torch.arange(hw).repeat(B, 1)
+    src[is_dirty] = hw + num
+    return kv.to(torch.bfloat16).to(DEV), src.to(torch.int32), is_dirty
+
+
 @pytest.mark.parametrize("B,H,nq,n_tiles,qsplit", [(2, 2, 120, 64, False), (3, 4, 576, 128, True), (1, 12, 576, 256, True)])
 def test_attention_tiled_equals_dense_on_gathered_rows(B, H, nq, n_tiles, qsplit):
-    """Piece p of tile t of batch b from the live rows or from the table through piece_src == the dense call on the same rows gathered into
-    one [B, 64 n_tiles, 2d] buffer: same kernel, same key order -> bit-identical outputs."""
+    """Every key slot through its own source row of the one K|V buffer == the dense call on the same rows gathered into a
+    [B, 64 n_tiles, 2d] buffer: same kernel, same key order -> bit-identical outputs."""
     o = ops()
     dh = 64
     d = H * dh
-    g = torch.Generator().manual_seed(5)
-    table = torch.randn(n_tiles * 64, 2 * d, generator=g).to(torch.bfloat16).to(DEV)
-    is_live = torch.rand(B, n_tiles, 8, generator=g) < 0.4
-    is_live[0, 0] = torch.tensor([True, False, True, True, False, False, True, False])
-    n_l = int(is_live.sum())
-    live = torch.randn((n_l + 3) * 8, 2 * d, generator=g).to(torch.bfloat16).to(DEV)
-    src = torch.empty(B, n_tiles, 8, dtype=torch.int32)
-    perm = torch.randperm(n_l, generator=g)
-    k = 0
-    for b in range(B):
-        for t in range(n_tiles):
-            for p in range(8):
-                if is_live[b, t, p]:
-                    src[b, t, p] = 8 * int(perm[k]); k += 1
-                else:
-                    src[b, t, p] = ~(64 * t + 8 * p)
-    dense = torch.empty(B, n_tiles * 64, 2 * d, dtype=torch.bfloat16, device=DEV)
-    for b in range(B):
-        for t in range(n_tiles):
-            for p in range(8):
-                r = int(src[b, t, p])
-                dense[b, 64 * t + 8 * p:64 * t + 8 * p + 8] = live[r:r + 8] if r >= 0 else table[~r:~r + 8]
-    q = torch.randn(B * nq, d, generator=g).to(DEV)
+    kv, src, _ = _row_case(B, H, n_tiles, 0.4, 5)
+    dense = kv[src.to(DEV).long().view(-1)].view(B * n_tiles * 64, 2 * d).contiguous()
+    q = torch.randn(B * nq, d, generator=torch.Generator().manual_seed(6)).to(DEV)
     qb = o.cast(q, qsplit)
-    got = o.attention_tiled(qb, live, table, src.to(DEV).contiguous().view(-1), batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=dh,
-                            scale=1.0 / math.sqrt(dh))
-    dk = dense.view(B * n_tiles * 64, 2 * d)
-    ref = o.attention(qb, (dk, None), (dk[:, d:], None), batch=B, n_heads=H, n_kv_heads=H, nq=nq, nkv=n_tiles * 64, dh=dh,
+    got = o.attention_tiled(qb, kv, src.to(DEV).contiguous(), batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=dh, scale=1.0 / math.sqrt(dh))
+    ref = o.attention(qb, (dense, None), (dense[:, d:], None), batch=B, n_heads=H, n_kv_heads=H, nq=nq, nkv=n_tiles * 64, dh=dh,
                       q_strides=(nq * d, d, dh), k_strides=(n_tiles * 64 * 2 * d, 2 * d, dh), v_strides=(n_tiles * 64 * 2 * d, 2 * d, dh),
                       scale=1.0 / math.sqrt(dh))
     assert torch.equal(got[0], ref[0])
@@ -194,103 +216,88 @@ def test_attention_tiled_equals_dense_on_gathered_rows(B, H, nq, n_tiles, qsplit
         assert torch.equal(got[1], ref[1])
 
 
-def _signed_case(B, H, nq, n_tiles, live_frac, seed, k_live_scale=1.0, k_tab_scale=1.0, v_scale=1.0):
-    """Random tiled stream with ONE copy of the queries: (q BF, live rows, table, piece_src [B, n_tiles, 8]); live fraction per batch."""
-    o = ops()
-    d = H * 64
-    g = torch.Generator().manual_seed(seed)
-    table = torch.randn(n_tiles * 64, 2 * d, generator=g)
-    table[:, :d] *= k_tab_scale
-    table[:, d:] *= v_scale
-    table = table.to(torch.bfloat16).to(DEV)
-    fr = torch.tensor(live_frac if isinstance(live_frac, (list, tuple)) else [live_frac] * B).view(B, 1, 1)
-    is_live = torch.rand(B, n_tiles, 8, generator=g) < fr
-    n_l = int(is_live.sum())
-    live = torch.randn((n_l + 1) * 8, 2 * d, generator=g)
-    live[:, :d] *= k_live_scale
-    live[:, d:] *= v_scale
-    live = live.to(torch.bfloat16).to(DEV)
-    e = torch.arange(n_tiles * 8).view(1, n_tiles, 8)
-    rank = (torch.cumsum(is_live.permute(1, 0, 2).reshape(-1).int(), 0) - 1).view(n_tiles, B, 8).permute(1, 0, 2)     # (tile, scene, piece) order
-    src = torch.where(is_live, 8 * rank, ~(8 * e).expand(B, n_tiles, 8)).to(torch.int32)
-    q = torch.randn(nq, d, generator=g).to(DEV)
-    return o.cast(q, True), live, table, src, is_live
-
-
 def test_scene_pairs_vs_numpy():
     o = ops()
     B, nt = 4, 96
-    _, _, _, src, is_live = _signed_case(B, 2, 64, nt, [0.3, 0.0, 0.7, 0.05], 3)
-    pair_src, pair_info = o.bev_scene_pairs(src.to(DEV).contiguous().view(-1), B, nt)
+    hw = nt * 64
+    _, src, _ = _row_case(B, 2, nt, [0.3, 0.0, 0.7, 0.05], 3)
+    pair_src, pair_info = o.bev_scene_pairs(src.to(DEV).contiguous(), B, nt, hw)
     ps, pi = pair_src.cpu().numpy(), pair_info.cpu().numpy()
     s_np = src.numpy()
     for b in range(B):
-        lv = [(int(s_np[b, t, p]), 8 * (8 * t + p)) for t in range(nt) for p in range(8) if s_np[b, t, p] >= 0]
-        n_pt = (len(lv) + 3) // 4
+        lv = [(int(s_np[b, e]), e) for e in range(hw) if s_np[b, e] >= hw]
+        n_pt = (len(lv) + 31) // 32
         use = n_pt < nt
         assert pi[b, 1] == int(use) and pi[b, 0] == (n_pt if use else 0)
         if not use:
             continue
-        for j, (row, trow) in enumerate(lv):
-            assert ps[b, j // 4, j % 4] == row and ps[b, j // 4, 4 + j % 4] == ~trow
-        for j in range(len(lv), 4 * n_pt):                         # padding: table piece 0 in both halves
-            assert ps[b, j // 4, j % 4] == -1 and ps[b, j // 4, 4 + j % 4] == -1
+        for j, (row, e) in enumerate(lv):
+            assert ps[b, j // 32, j % 32] == row and ps[b, j // 32, 32 + j % 32] == e
+        for j in range(len(lv), 32 * n_pt):                        # padding: table row 0 in both halves
+            assert ps[b, j // 32, j % 32] == 0 and ps[b, j // 32, 32 + j % 32] == 0
 
 
-def _full_reference(o, qb, live, table, src, B, H, nq, n_tiles):
+def _shared_q(o, H, nq, seed):
+    return o.cast(torch.randn(nq, H * 64, generator=torch.Generator().manual_seed(seed)).to(DEV), True)
+
+
+def _full_reference(o, qb, kv, src, B, H, nq, n_tiles):
     d = H * 64
     qh = qb[0].unsqueeze(0).expand(B, nq, d).reshape(B * nq, d).contiguous()
     ql = qb[1].unsqueeze(0).expand(B, nq, d).reshape(B * nq, d).contiguous()
-    return o.attention_tiled((qh, ql), live, table, src.to(DEV).contiguous().view(-1), batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=64,
-                             scale=1.0 / 8.0)
+    return o.attention_tiled((qh, ql), kv, src.to(DEV).contiguous(), batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=64, scale=1.0 / 8.0)
 
 
-def _signed(o, qb, live, table, src, B, H, nq, n_tiles):
-    srcd = src.to(DEV).contiguous().view(-1)
-    pair_src, pair_info = o.bev_scene_pairs(srcd, B, n_tiles)
-    tot = o.attention_stream_totals(qb, table, n_heads=H, nq=nq, nkv=n_tiles * 64, dh=64, scale=1.0 / 8.0)
-    out = o.attention_tiled_signed(qb, live, table, srcd, pair_src, pair_info, tot, batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=64,
-                                   scale=1.0 / 8.0, shared_q=True)
+def _signed(o, qb, kv, src, B, H, nq, n_tiles):
+    hw = n_tiles * 64
+    srcd = src.to(DEV).contiguous()
+    pair_src, pair_info = o.bev_scene_pairs(srcd, B, n_tiles, hw)
+    tot = o.attention_stream_totals(qb, kv[:hw], n_heads=H, nq=nq, nkv=hw, dh=64, scale=1.0 / 8.0)
+    out = o.attention_tiled_signed(qb, kv, srcd, pair_src, pair_info, tot, batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=64, scale=1.0 / 8.0,
+                                   shared_q=True)
     return out, pair_info
 
 
 @pytest.mark.parametrize("B,H,nq,n_tiles,fr", [(3, 2, 120, 64, 0.35), (2, 4, 576, 128, [0.4, 0.9]), (4, 12, 576, 256, [0.0, 0.2, 0.45, 0.6]),
                                                (1, 2, 120, 67, 0.3)])
 def test_attention_tiled_signed_matches_full_stream(B, H, nq, n_tiles, fr):
-    """TOTALS(table) - table terms at the live positions + live rows == the full stream, up to fp32 accumulation order; batches whose
-    pair list is not shorter (live > 50 %) run their full list inside the same launch."""
+    """TOTALS(table) - table rows of the dirty cells + their computed rows == the full stream, up to fp32 accumulation order; batches
+    whose pair list is not shorter (dirty > 50 %) run their full list inside the same launch."""
     o = ops()
-    qb, live, table, src, is_live = _signed_case(B, H, nq, n_tiles, fr, 17)
-    ref = _full_reference(o, qb, live, table, src, B, H, nq, n_tiles)
-    (oh, ol), pair_info = _signed(o, qb, live, table, src, B, H, nq, n_tiles)
+    kv, src, is_dirty = _row_case(B, H, n_tiles, fr, 17)
+    qb = _shared_q(o, H, nq, 18)
+    ref = _full_reference(o, qb, kv, src, B, H, nq, n_tiles)
+    (oh, ol), pair_info = _signed(o, qb, kv, src, B, H, nq, n_tiles)
     pi = pair_info.cpu().numpy()
-    want_use = [int((int(is_live[b].sum()) + 3) // 4 < n_tiles) for b in range(B)]
+    want_use = [int((int(is_dirty[b].sum()) + 31) // 32 < n_tiles) for b in range(B)]
     assert pi[:, 1].tolist() == want_use
     got, want = o.to_f32((oh, ol)).view(B, nq, -1), o.to_f32(ref).view(B, nq, -1)
     scale = want.abs().max().item()
-    for b in range(B):                                            # (full-list batches: same stream, the row sum kept in two halves)
+    for b in range(B):                                            # (full-list batches: same stream, the signed row sum takes another path)
         assert (got[b] - want[b]).abs().max().item() < (2e-5 if want_use[b] else 2e-6) * max(scale, 1.0), (b, (got[b] - want[b]).abs().max().item())
 
 
 @pytest.mark.parametrize("kind", ["cancel", "overflow"])
 def test_attention_tiled_signed_falls_back_when_unusable(kind):
-    """(a) The live keys score far below the table keys they replace: what is left after the subtraction is < 1/16 of the table total
-    -> the (batch, head) is flagged and redone over its full stream (then bit-identical to the full stream).  (b) live scores beyond
+    """(a) The computed keys score far below the table keys they replace: what is left after the subtraction is < 1/16 of the table total
+    -> the (batch, head) is flagged and redone over its full stream (then bit-identical to the full stream).  (b) computed scores beyond
     2^128: the signed sums are not finite -> same re-run (which itself falls back to the classic softmax form)."""
     o = ops()
     B, H, nq, n_tiles = 2, 2, 120, 64
+    hw = n_tiles * 64
     if kind == "cancel":
-        qb, live, table, src, _ = _signed_case(B, H, nq, n_tiles, [0.45, 0.3], 23, k_live_scale=0.01, k_tab_scale=6.0)
-        # the clean positions must hold almost no mass: shrink their table keys (the live positions keep the large ones)
-        clean = (src < 0).any(0)                                 # [n_tiles, 8]: clean in some batch -> make those table rows small
-        t32 = table.float()
-        rows = clean.view(-1).repeat_interleave(8).to(DEV)
-        t32[rows, :H * 64] *= 0.002
-        table = t32.to(torch.bfloat16)
+        kv, src, is_dirty = _row_case(B, H, n_tiles, [0.45, 0.3], 23, k_new_scale=0.01, k_tab_scale=6.0)
+        # the cells that stay clean in some batch must hold almost no mass: shrink their table keys (cells dirty in BOTH keep the large ones)
+        clean_somewhere = (~is_dirty).any(0).to(DEV)
+        t32 = kv.float()
+        tab = t32[:hw]
+        tab[clean_somewhere, :H * 64] *= 0.002
+        kv = t32.to(torch.bfloat16)
     else:
-        qb, live, table, src, _ = _signed_case(B, H, nq, n_tiles, [0.45, 0.3], 23, k_live_scale=400.0)
-    ref = _full_reference(o, qb, live, table, src, B, H, nq, n_tiles)
-    (oh, ol), _ = _signed(o, qb, live, table, src, B, H, nq, n_tiles)
+        kv, src, _ = _row_case(B, H, n_tiles, [0.45, 0.3], 23, k_new_scale=400.0)
+    qb = _shared_q(o, H, nq, 24)
+    ref = _full_reference(o, qb, kv, src, B, H, nq, n_tiles)
+    (oh, ol), _ = _signed(o, qb, kv, src, B, H, nq, n_tiles)
     assert torch.isfinite(o.to_f32((oh, ol))).all()
     assert torch.equal(oh, ref[0]) and torch.equal(ol, ref[1])
 
