@@ -287,10 +287,16 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
     }
     const int col0 = 16 * J * wid + 4 * J * g4;                  // this lane's first column (4 J consecutive ones)
 
-    // work order: every workgroup takes one CONTIGUOUS run of the (tile, scene, piece)-ordered list, so the scenes that share a
-    // positional table tile are served back to back by the same workgroup (first read from HBM, repeats from the XCD's L2)
-    const int64_t chunk = (n_groups + gridDim.x - 1) / gridDim.x;
-    const int64_t g_begin = (int64_t)blockIdx.x * chunk, g_end = g_begin + chunk < n_groups ? g_begin + chunk : n_groups;
+    // work order: the list is in (tile, scene, piece) order, so neighbouring groups need the same rows of the positional table.  Each
+    // XCD (hardware deals block ids round-robin over the 8 XCDs, each with its own 4 MiB L2) takes one CONTIGUOUS eighth of the list
+    // and its workgroups walk it INTERLEAVED (workgroup r of R takes groups r, r + R, ...): at any time the XCD works on ~R
+    // consecutive groups = a few tiles, whose table rows (192 KB per tile) are then L2 hits for everyone but the first reader.  (One
+    // contiguous run per workgroup keeps 32 different table tiles in flight per XCD -- 6 MB, more than the L2.)
+    const int nxcd = gridDim.x >= 8 && gridDim.x % 8 == 0 ? 8 : 1;
+    const int xcd = (int)blockIdx.x % nxcd, wg_r = (int)blockIdx.x / nxcd, wg_R = (int)gridDim.x / nxcd;
+    const int64_t per_x = (n_groups + nxcd - 1) / nxcd;
+    const int64_t x_begin = (int64_t)xcd * per_x, x_end = x_begin + per_x < n_groups ? x_begin + per_x : n_groups;
+    const int64_t g_begin = x_begin + wg_r, g_end = x_end, g_step = wg_R;       // this workgroup: g_begin, g_begin + g_step, ... < g_end
     // halo index of slot tid (< 192) of group g: piece j = tid / 24 (code = live_list[8 g + j]), halo cell tid % 24; threads with
     // tid % 24 == 0 also return the piece code (-1 past the end of the list)
     auto load_idx = [&](int64_t g, int &code_out) -> int {
@@ -411,7 +417,7 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
     {
         int c0, c1;
         const int i0 = load_idx(g_begin, c0);
-        const int i1 = g_begin + 1 < g_end ? load_idx(g_begin + 1, c1) : (c1 = -1, -1);
+        const int i1 = g_begin + g_step < g_end ? load_idx(g_begin + g_step, c1) : (c1 = -1, -1);
         store_idx(idxh, i0, c0);
         store_idx(idxh + 256, i1, c1);
     }
@@ -421,11 +427,10 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
     __syncthreads();
     conv_tile(idxh, 0);
     int buf = 0;
-    for (int64_t g = g_begin; g < g_end; ++g) {
-        const int64_t it = g - g_begin;
+    for (int64_t g = g_begin, it = 0; g < g_end; g += g_step, ++it) {
         __syncthreads();                                          // B1: t[buf] complete, halo buffer free, part[buf] free
         const int32_t *ih_cur = idxh + (it & 1) * 256, *ih_nx = idxh + ((it + 1) & 1) * 256;
-        const bool has_nx = g + 1 < g_end, has_n2 = g + 2 < g_end;
+        const bool has_nx = g + g_step < g_end, has_n2 = g + 2 * g_step < g_end;
         if (has_nx) dma_halo(ih_nx);
         // piece codes of THIS group for pass 2 (its slot of idxh is overwritten before B2): lane's cell of group gq belongs to piece
         // 2 gq + (l15 >> 3)
@@ -433,7 +438,7 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) code_cur[gq] = ih_cur[200 + 2 * gq + (l15 >> 3)];
         int c2 = -1;
-        const int i2 = has_n2 ? load_idx(g + 2, c2) : -1;
+        const int i2 = has_n2 ? load_idx(g + 2 * g_step, c2) : -1;
         // ---- pass 1: per-wave (mean, M2) of every cell over this wave's 16 J columns ----
         float *pw = part + ((buf * NWV + wid) * TCELLS) * 2;
 #pragma unroll 1
