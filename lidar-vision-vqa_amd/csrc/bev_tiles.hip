@@ -536,6 +536,287 @@ __global__ void __launch_bounds__(512) k_tile_tokens(TokArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fused K|V kernel: from the pillar features straight to the K|V rows of the dirty cells, without the d-wide token.
+//   x   = LayerNorm(Wp t + bp) * gamma + beta + PE[e]          (vat_lidar.py:222-248; t = GELU(dwconv3x3(pillars)) in R^64)
+//   K|V = W_kv x + b_kv                                          (vat_blocks.py:42, in_proj rows d .. 3d)
+// LayerNorm of a linear map of t is a per-row rescale of another linear map of t:  y - mean(y) = Wc t + bc  (Wc, bc = Wp, bp with
+// their means over the d outputs removed), var(y) = |Wc t + bc|^2 / d = (|R t + r0|^2 + c0) / d  with R the 64 x 64 triangular factor
+// of [Wc bc], so
+//   K|V = rstd (M t + m0) + T[e],   M = W_kv diag(gamma) Wc  [2d, 64],  m0 = W_kv (gamma * bc),  T[e] = W_kv (beta + PE[e]) + b_kv,
+//   rstd = 1 / sqrt((|R t + r0|^2 + c0) / d + eps)
+// -- exact algebra (folded once per weights version on the host, fusion.VATLiDAR._kv_fold), and the 768-deep K|V projection becomes a
+// 64-deep one.  Same skeleton as k_tile_tokens (live pieces, halo by LDS-DMA, conv in LDS, W fragments in registers, dirty cells
+// stored compactly); a workgroup owns ONE column half (K or V: blockIdx bit 3), the product is computed once, the "statistics pass"
+// is one 16-row tile of R per wave and 16-cell group.
+// ---------------------------------------------------------------------------------------------------------
+struct KvArgs {
+    const float *feat;            // [M, 64] pillar features
+    const int32_t *idx;           // [S, H, W] pillar row or -1
+    const int32_t *live_list;     // flat piece indices (t * S + s) * 8 + p
+    const int2 *piece_dirty;      // per live piece: (first dirty-row number, dirty mask)
+    const int32_t *counts;        // counts[0] = live pieces
+    const float *w9, *b9;         // depthwise conv [64, 9], [64]
+    const uint16_t *mh, *ml;      // M [2 N, 64] bf16 hi / lo
+    const float *m0;              // [2 N]
+    const uint16_t *rh, *rl;      // R [64, 64] bf16 hi / lo
+    const float *r0;              // [64]
+    float c0, inv_d, eps;
+    const float *te;              // T [H*W (tile-major), 2 N] fp32
+    int S, H, W;
+    uint16_t *out;                // K|V rows [dirty rows, 2 N] bf16
+};
+
+template <int J, bool X3>
+__global__ void __launch_bounds__(512) k_tile_kv(KvArgs a) {
+    constexpr int N = 128 * J, C = 64, NWV = 8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // LDS map
+    uint16_t *t_hi = reinterpret_cast<uint16_t *>(smem);                      // [2][64][64] bf16, 128-byte rows, chunk-swizzled
+    uint16_t *t_lo = t_hi + 2 * TCELLS * C;                                   // [2][64][64]
+    float *halo = reinterpret_cast<float *>(t_lo + 2 * TCELLS * C);           // [192][64] fp32 pillar rows of the 8 halos (live slots only)
+    int32_t *idxh = reinterpret_cast<int32_t *>(halo + NSLOT * C);            // [2][256]: 192 halo indices + 8 piece codes at [200..207]
+    float *part = reinterpret_cast<float *>(idxh + 2 * 256);                  // [2][4 row tiles of R][64 cells]
+    float *pbias = part + 2 * 4 * TCELLS;                                     // [N] m0 of this half
+    float *w9s = pbias + N;                                                   // [9][64]
+    float *b9s = w9s + 9 * C;                                                 // [64]
+    float *r0s = b9s + C;                                                     // [64]
+    uint16_t *r_hi = reinterpret_cast<uint16_t *>(r0s + C);                   // [64][64] bf16 (row-major, fragment reads are 16 B)
+    uint16_t *r_lo = r_hi + C * C;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const int tw = a.W / TS;
+    const int n_live = a.counts[0];                             // live pieces
+    const int64_t n_groups = ((int64_t)n_live + NPIECE - 1) / NPIECE;
+
+    // work order as k_tile_tokens (each XCD one contiguous eighth of the list, its workgroups interleaved); the two column halves of
+    // a group run on the same XCD (block id bit 3, or bit 0 on a grid that is not a multiple of 16)
+    const bool x8 = gridDim.x >= 16 && gridDim.x % 16 == 0;
+    const int nxcd = x8 ? 8 : 1;
+    const int xcd = x8 ? (int)blockIdx.x & 7 : 0;
+    const int half = x8 ? ((int)blockIdx.x >> 3) & 1 : (int)blockIdx.x & 1;
+    const int wg_r = x8 ? (int)blockIdx.x >> 4 : (int)blockIdx.x >> 1, wg_R = x8 ? (int)gridDim.x >> 4 : ((int)gridDim.x + 1) >> 1;
+    const int64_t per_x = (n_groups + nxcd - 1) / nxcd;
+    const int64_t x_begin = (int64_t)xcd * per_x, x_end = x_begin + per_x < n_groups ? x_begin + per_x : n_groups;
+    const int64_t g_begin = x_begin + wg_r, g_end = x_end, g_step = wg_R;
+    const int ncol0 = half * N;                                  // this workgroup's first output column
+
+    for (int e = tid; e < N; e += 512) pbias[e] = a.m0[ncol0 + e];
+    for (int e = tid; e < 9 * C; e += 512) w9s[e] = a.w9[(e % C) * 9 + e / C];
+    if (tid < C) { b9s[tid] = a.b9 ? a.b9[tid] : 0.f; r0s[tid] = a.r0[tid]; }
+    for (int e = tid; e < C * C / 8; e += 512) {
+        reinterpret_cast<u32x4 *>(r_hi)[e] = reinterpret_cast<const u32x4 *>(a.rh)[e];
+        if (X3) reinterpret_cast<u32x4 *>(r_lo)[e] = reinterpret_cast<const u32x4 *>(a.rl)[e];
+    }
+
+    // M fragments (A operand) in registers: lane (m = l15, kc = g4) holds M[ncol0 + n(m, j)][8 kc .. +7] and [32 + 8 kc .. +7]
+    bf16x8 wf[J][2], wfl[X3 ? J : 1][2];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int n = ncol0 + 16 * J * wid + 4 * J * (l15 >> 2) + 4 * j + (l15 & 3);
+        wf[j][0] = *reinterpret_cast<const bf16x8 *>(a.mh + (int64_t)n * C + 8 * g4);
+        wf[j][1] = *reinterpret_cast<const bf16x8 *>(a.mh + (int64_t)n * C + 32 + 8 * g4);
+        if (X3) {
+            wfl[j][0] = *reinterpret_cast<const bf16x8 *>(a.ml + (int64_t)n * C + 8 * g4);
+            wfl[j][1] = *reinterpret_cast<const bf16x8 *>(a.ml + (int64_t)n * C + 32 + 8 * g4);
+        }
+    }
+    const int col0 = 16 * J * wid + 4 * J * g4;                  // this lane's first column inside the half (4 J consecutive ones)
+
+    auto load_idx = [&](int64_t g, int &code_out) -> int {
+        code_out = -1;
+        if (tid >= NSLOT) return -1;
+        const int j = tid / PHALO, hc = tid - j * PHALO;
+        const int64_t k = g * NPIECE + j;
+        if (k >= n_live) return -1;
+        const int code = a.live_list[k];
+        code_out = code;
+        const int p = code & 7, ts = code >> 3, t = ts / a.S, sc = ts - t * a.S;
+        int y0, x0;
+        piece_origin(t, p, tw, y0, x0);
+        const int gy = y0 - 1 + hc / PW, gx = x0 - 1 + hc % PW;
+        return (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? a.idx[((int64_t)sc * a.H + gy) * a.W + gx] : -1;
+    };
+    auto store_idx = [&](int32_t *ih, int v, int code) {
+        if (tid < NSLOT) {
+            ih[tid] = v;
+            if (tid % PHALO == 0) ih[200 + tid / PHALO] = code;
+        }
+    };
+    auto dma_halo = [&](const int32_t *ih) {
+        for (int q = wid; q < NSLOT / 4; q += NWV) {
+            const int slot = q * 4 + (lane >> 4);
+            const int row = ih[slot];
+            if (row >= 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.feat + (int64_t)row * C + 4 * l15),
+                                                 (__attribute__((address_space(3))) void *)(halo + q * 4 * C), 16, 0, 0);
+        }
+    };
+    // depthwise 3x3 + GELU: the SAME tap order and fmaf chain as k_tile_tokens / k_dwconv3x3_gelu
+    auto conv_tile = [&](const int32_t *ih, int buf) {
+        const int cell = tid >> 3, cg = (tid & 7) * 8, hb = (cell >> 3) * PHALO, cy = (cell >> 2) & 1, cx = cell & 3;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = b9s[cg + c];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int slot = hb + (cy + rr) * PW + cx + k;
+                if (ih[slot] >= 0) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(halo + slot * C + cg), v1 = *reinterpret_cast<const f32x4 *>(halo + slot * C + cg + 4);
+                    const f32x4 k0 = *reinterpret_cast<const f32x4 *>(w9s + (rr * 3 + k) * C + cg), k1 = *reinterpret_cast<const f32x4 *>(w9s + (rr * 3 + k) * C + cg + 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { acc[c] = fmaf(v0[c], k0[c], acc[c]); acc[4 + c] = fmaf(v1[c], k1[c], acc[4 + c]); }
+                }
+            }
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float y0 = gelu_erf(acc[2 * c]), y1 = gelu_erf(acc[2 * c + 1]);
+            hi[c] = pack_bf16(y0, y1);
+            lo[c] = pack_bf16(y0 - __uint_as_float(hi[c] << 16), y1 - __uint_as_float(hi[c] & 0xffff0000u));
+        }
+        const int ch = (tid & 7) ^ ((cell >> 1) & 7);
+        *reinterpret_cast<u32x4 *>(t_hi + (buf * TCELLS + cell) * C + ch * 8) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        if (X3) *reinterpret_cast<u32x4 *>(t_lo + (buf * TCELLS + cell) * C + ch * 8) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    };
+    constexpr int JH = J / 2;
+    static_assert(J % 2 == 0, "even J");
+    auto load_t = [&](int buf, int gq, bf16x8 &th0, bf16x8 &th1, bf16x8 &tl0, bf16x8 &tl1) {
+        const int row = gq * 16 + l15;
+        const int c0 = (g4 ^ ((row >> 1) & 7)) * 8, c1 = ((4 + g4) ^ ((row >> 1) & 7)) * 8;
+        th0 = *reinterpret_cast<const bf16x8 *>(t_hi + (buf * TCELLS + row) * C + c0);
+        th1 = *reinterpret_cast<const bf16x8 *>(t_hi + (buf * TCELLS + row) * C + c1);
+        if (X3) {
+            tl0 = *reinterpret_cast<const bf16x8 *>(t_lo + (buf * TCELLS + row) * C + c0);
+            tl1 = *reinterpret_cast<const bf16x8 *>(t_lo + (buf * TCELLS + row) * C + c1);
+        }
+    };
+    auto opaque = [](const float *p) { asm volatile("" : "+v"(p)); return p; };
+    auto product = [&](auto hf_tag, const bf16x8 &th0, const bf16x8 &th1, const bf16x8 &tl0, const bf16x8 &tl1, f32x4 (&acc)[JH]) {
+        constexpr int HF = decltype(hf_tag)::value;
+        const float *pb = opaque(pbias + col0);
+#pragma unroll
+        for (int jj = 0; jj < JH; ++jj) {
+            const int j = HF * JH + jj;
+            acc[jj] = *reinterpret_cast<const f32x4 *>(pb + 4 * j);
+            acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], th0, acc[jj], 0, 0, 0);
+            acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], th1, acc[jj], 0, 0, 0);
+            if (X3) {
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], tl0, acc[jj], 0, 0, 0);
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], tl1, acc[jj], 0, 0, 0);
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfl[j][0], th0, acc[jj], 0, 0, 0);
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfl[j][1], th1, acc[jj], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- prologue: group 0 staged synchronously, indices of the next group in LDS ----
+    if (tid < 256) { idxh[tid] = -1; idxh[256 + tid] = -1; }
+    __syncthreads();
+    if (g_begin >= g_end) return;
+    {
+        int c0, c1;
+        const int i0 = load_idx(g_begin, c0);
+        const int i1 = g_begin + g_step < g_end ? load_idx(g_begin + g_step, c1) : (c1 = -1, -1);
+        store_idx(idxh, i0, c0);
+        store_idx(idxh + 256, i1, c1);
+    }
+    __syncthreads();
+    dma_halo(idxh);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_tile(idxh, 0);
+    int buf = 0;
+    for (int64_t g = g_begin, it = 0; g < g_end; g += g_step, ++it) {
+        __syncthreads();                                          // B1: t[buf] complete, halo buffer free, part[buf] free
+        const int32_t *ih_cur = idxh + (it & 1) * 256, *ih_nx = idxh + ((it + 1) & 1) * 256;
+        const bool has_nx = g + g_step < g_end, has_n2 = g + 2 * g_step < g_end;
+        if (has_nx) dma_halo(ih_nx);
+        int code_cur[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) code_cur[gq] = ih_cur[200 + 2 * gq + (l15 >> 3)];
+        int c2 = -1;
+        const int i2 = has_n2 ? load_idx(g + 2 * g_step, c2) : -1;
+        // ---- |R t + r0|^2 per cell: wave w takes the 16-row tile w & 3 of R for the two 16-cell groups 2 (w >> 2), 2 (w >> 2) + 1 ----
+        {
+            const int rt = wid & 3;
+            const uint16_t *rp = r_hi + (16 * rt + l15) * C + 8 * g4, *rpl = r_lo + (16 * rt + l15) * C + 8 * g4;
+            const bf16x8 ra0 = *reinterpret_cast<const bf16x8 *>(rp), ra1 = *reinterpret_cast<const bf16x8 *>(rp + 32);
+            bf16x8 rl0 = ra0, rl1 = ra1;
+            if (X3) { rl0 = *reinterpret_cast<const bf16x8 *>(rpl); rl1 = *reinterpret_cast<const bf16x8 *>(rpl + 32); }
+            const f32x4 rinit = *reinterpret_cast<const f32x4 *>(r0s + 16 * rt + 4 * g4);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int gq = 2 * (wid >> 2) + u;
+                bf16x8 th0, th1, tl0, tl1;
+                load_t(buf, gq, th0, th1, tl0, tl1);
+                f32x4 v = rinit;
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra0, th0, v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra1, th1, v, 0, 0, 0);
+                if (X3) {
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra0, tl0, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra1, tl1, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl0, th0, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl1, th1, v, 0, 0, 0);
+                }
+                float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                sq += __shfl_xor(sq, 16);
+                sq += __shfl_xor(sq, 32);
+                if (g4 == 0) part[(buf * 4 + rt) * TCELLS + gq * 16 + l15] = sq;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's halo DMA (next group) has landed
+        __syncthreads();                                          // B2: partial sums complete; every wave's DMA landed; codes of this group read
+        store_idx(idxh + (it & 1) * 256, i2, c2);
+        if (has_nx) conv_tile(ih_nx, buf ^ 1);
+        // ---- product, rescale, + table, store ----
+        {
+            const float *pr = part + buf * 4 * TCELLS;
+#pragma unroll 1
+            for (int gq = 0; gq < 4; ++gq) {
+                const int cell = gq * 16 + l15;
+                const int code = gq == 0 ? code_cur[0] : gq == 1 ? code_cur[1] : gq == 2 ? code_cur[2] : code_cur[3];
+                const bool in_list = code >= 0;
+                const int64_t prow = in_list ? (int64_t)((code >> 3) / a.S) * TCELLS + (code & 7) * PCELLS + (cell & 7) : 0;
+                const int2 pd = in_list ? a.piece_dirty[g * NPIECE + (cell >> 3)] : make_int2(0, 0);
+                const bool valid = (pd.y >> (cell & 7)) & 1;
+                const int64_t orow = pd.x + __popc((unsigned)pd.y & ((1u << (cell & 7)) - 1u));
+                const float *tep = a.te + prow * (2 * N) + ncol0 + col0;
+                f32x4 te0[JH], te1[JH];
+#pragma unroll
+                for (int jj = 0; jj < JH; ++jj) te0[jj] = *reinterpret_cast<const f32x4 *>(tep + 4 * jj);
+#pragma unroll
+                for (int jj = 0; jj < JH; ++jj) te1[jj] = *reinterpret_cast<const f32x4 *>(tep + 4 * (JH + jj));
+                const float ss = (pr[cell] + pr[TCELLS + cell]) + (pr[2 * TCELLS + cell] + pr[3 * TCELLS + cell]) + a.c0;
+                const float rstd = 1.0f / sqrtf(ss * a.inv_d + a.eps);
+                bf16x8 th0, th1, tl0, tl1;
+                load_t(buf, gq, th0, th1, tl0, tl1);
+                uint16_t *dst = a.out + orow * (2 * N) + ncol0 + col0;
+                auto half_out = [&](auto hf_tag, const f32x4 (&te)[JH]) {
+                    constexpr int HF = decltype(hf_tag)::value;
+                    f32x4 acc[JH];
+                    product(hf_tag, th0, th1, tl0, tl1, acc);
+                    uint32_t oh[2 * JH];
+#pragma unroll
+                    for (int jj = 0; jj < JH; ++jj) {
+                        oh[2 * jj] = pack_bf16(acc[jj][0] * rstd + te[jj][0], acc[jj][1] * rstd + te[jj][1]);
+                        oh[2 * jj + 1] = pack_bf16(acc[jj][2] * rstd + te[jj][2], acc[jj][3] * rstd + te[jj][3]);
+                    }
+                    if (valid) {
+#pragma unroll
+                        for (int q = 0; q < 2 * JH; q += 2)
+                            *reinterpret_cast<uint2 *>(dst + 2 * (2 * HF * JH + q)) = make_uint2(oh[q], oh[q + 1]);
+                    }
+                };
+                half_out(std::integral_constant<int, 0>{}, te0);
+                half_out(std::integral_constant<int, 1>{}, te1);
+            }
+        }
+        buf ^= 1;
+    }
+}
+
 }  // namespace bt
 
 // =================================================================================================
@@ -563,6 +844,48 @@ extern "C" int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, 
     hipLaunchKernelGGL(bt::k_piece_compact, dim3(nb), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, total, (const int32_t *)block_cnt, nb,
                        row_base, live_list, reinterpret_cast<int2 *>(piece_dirty), row_src, counts);
     return lvq_launch_status();
+}
+
+template <int J> static int launch_tile_kv(const bt::KvArgs &a, bool x3, int64_t cap_tiles, hipStream_t st) {
+    const size_t lds = (size_t)2 * 2 * bt::TCELLS * 64 * 2 + (size_t)bt::NSLOT * 64 * 4 + 2 * 256 * 4 + (size_t)2 * 4 * bt::TCELLS * 4 +
+                       (size_t)128 * J * 4 + 9 * 64 * 4 + 64 * 4 + 64 * 4 + (size_t)2 * 64 * 64 * 2;
+    static LvqLdsOnce once;
+    if (!lvq_ensure_lds(once, {(const void *)bt::k_tile_kv<J, false>, (const void *)bt::k_tile_kv<J, true>}, lds)) return LVQ_ELAUNCH;
+    int64_t grid = (int64_t)lvq_cu_count();
+    if (grid > cap_tiles) grid = cap_tiles;
+    grid *= 2;                                                   // two column halves (K, V) per group
+    if (x3) hipLaunchKernelGGL((bt::k_tile_kv<J, true>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    else    hipLaunchKernelGGL((bt::k_tile_kv<J, false>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    return lvq_launch_status();
+}
+
+// K|V rows of the dirty cells straight from the pillar features (k_tile_kv): refine conv + GELU -> t, then
+// kv = rstd (M t + m0) + T[key] with rstd = 1 / sqrt((|R t + r0|^2 + c0) / d_ln + eps).  n = d (the K and the V half are n columns each).
+extern "C" int lvq_bev_tile_kv(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *piece_dirty,
+                               const int32_t *counts, int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9,
+                               const lvq_bf16 *m, const lvq_bf16 *m_lo, const float *m0, const lvq_bf16 *r, const lvq_bf16 *r_lo, const float *r0,
+                               float c0, int d_ln, float eps, const float *t_tiled, int n, lvq_bf16 *kv, lvq_stream_t stream) {
+    if (batch <= 0 || ny <= 0 || nx <= 0 || cap_tiles <= 0 || d_ln <= 0 || !idx_map || !live_list || !piece_dirty || !counts || !w9 || !m || !m0 || !r ||
+        !r0 || !t_tiled || !kv)
+        return LVQ_EINVAL;
+    if ((m_lo == nullptr) != (r_lo == nullptr)) return LVQ_EINVAL;
+    if (c_in != 64 || (ny % 8) || (nx % 8) || (n % 256) || n < 256 || n > 1024) return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)pillar_feat | (uintptr_t)m | (uintptr_t)m_lo | (uintptr_t)r | (uintptr_t)r_lo | (uintptr_t)m0 | (uintptr_t)r0 | (uintptr_t)t_tiled |
+         (uintptr_t)kv) & 15)
+        return LVQ_EUNSUPPORTED;
+    bt::KvArgs a;
+    a.feat = pillar_feat; a.idx = idx_map; a.live_list = live_list; a.piece_dirty = reinterpret_cast<const int2 *>(piece_dirty); a.counts = counts;
+    a.w9 = w9; a.b9 = b9; a.mh = m; a.ml = m_lo; a.m0 = m0; a.rh = r; a.rl = r_lo; a.r0 = r0; a.c0 = c0; a.inv_d = 1.0f / (float)d_ln; a.eps = eps;
+    a.te = t_tiled; a.S = batch; a.H = ny; a.W = nx; a.out = kv;
+    hipStream_t st = lvq_s(stream);
+    const bool x3 = m_lo != nullptr;
+    switch (n / 128) {
+        case 2: return launch_tile_kv<2>(a, x3, cap_tiles, st);
+        case 4: return launch_tile_kv<4>(a, x3, cap_tiles, st);
+        case 6: return launch_tile_kv<6>(a, x3, cap_tiles, st);
+        case 8: return launch_tile_kv<8>(a, x3, cap_tiles, st);
+        default: return LVQ_EUNSUPPORTED;
+    }
 }
 
 // Per-scene pair list for lvq_attention_bf16_tiled_signed (see k_scene_pairs): pair_src [batch, cap_tiles, 64], pair_info [batch, 2].

@@ -153,7 +153,8 @@ class VATBlock(_HipModule):
         d, h = self.d_model, self.n_heads
         dh = d // h
         hw = n_tiles * 64
-        ops.linear_live_rows(x_rows, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, rows_dev, (d, 3 * d), tag="ca_kv_proj", out=kv[hw:])
+        if x_rows is not None:                                  # unfused route: tokens -> K|V GEMM; the fused kernel has filled kv[hw:] already
+            ops.linear_live_rows(x_rows, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, rows_dev, (d, 3 * d), tag="ca_kv_proj", out=kv[hw:])
         pair_src, pair_info = ops.bev_scene_pairs(row_src, B, n_tiles, hw)
         o = ops.attention_tiled_signed(qp, kv, row_src, pair_src, pair_info, totals, batch=B, n_heads=h, nq=nq, n_tiles=n_tiles,
                                        dh=dh, scale=1.0 / math.sqrt(dh), shared_q=True, tag="ca_attn")
@@ -170,7 +171,8 @@ class VATBlock(_HipModule):
         dh = d // h
         hw = n_tiles * 64
         q2 = self._self_attn(q2, B, nq)
-        ops.linear_live_rows(x_rows, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, rows_dev, (d, 3 * d), tag="ca_kv_proj", out=kv[hw:])
+        if x_rows is not None:
+            ops.linear_live_rows(x_rows, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, rows_dev, (d, 3 * d), tag="ca_kv_proj", out=kv[hw:])
         _, qn = ops.layernorm(q2, self.ca_ln.weight, self.ca_ln.bias, self.ca_ln.eps, self._split())
         _, qp = ops.linear(qn, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, out_bf=True, w_rows=(0, d), tag="ca_q_proj")
         o = ops.attention_tiled(qp, kv, row_src, batch=B, n_heads=h, nq=nq, n_tiles=n_tiles, dh=dh, scale=1.0 / math.sqrt(dh), tag="ca_attn")
@@ -341,15 +343,61 @@ class VATLiDAR(_HipModule):
                                    self.refine[0].bias, self._w(self.proj.weight), self.proj.bias, self.norm_tokens.weight, self.norm_tokens.bias,
                                    self.norm_tokens.eps, self._pe_tiled(H, W, feat.device), out_lo=False, tag="bev_proj_ln")
 
+    def _kv_fold(self, C: int, H: int, W: int, dev):
+        """LayerNorm and the K|V projection folded onto the 64-channel conv token (csrc/bev_tiles.hip: k_tile_kv; exact algebra):
+            K|V = W_kv (LN(Wp t + bp) + PE) + b_kv = rstd (M t + m0) + T[key],  rstd = 1 / sqrt((|R t + r0|^2 + c0) / d + eps)
+        -> (R BF [64, 64], r0 [64], c0, per layer (M BF [2d, 64], m0 [2d], T [HW, 2d] fp32 in tile-major key order)), cached per weights
+        version and precision mode.  The small factors are folded in fp64 (model-load-time plumbing, like folding a BatchNorm); the
+        table T runs through lvq_gemm_bf16 in the mode's operand form."""
+        params = [self.proj.weight, self.proj.bias, self.norm_tokens.weight, self.norm_tokens.bias, self.geo_mlp[0].weight, self.geo_mlp[0].bias,
+                  self.geo_mlp[2].weight, self.geo_mlp[2].bias, self.view_embed]
+        for blk in self.blocks:
+            params += [blk.ca.in_proj_weight, blk.ca.in_proj_bias]
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(),)
+        key = ("kv_fold", H, W, dev)
+        hit = self._pe_cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        split = self._split()
+        d = self.d_model
+        f64 = lambda p: p.detach().to(device=dev, dtype=torch.float64)
+        wp, bp = f64(self.proj.weight).view(d, C), f64(self.proj.bias)
+        wc, bc = wp - wp.mean(0, keepdim=True), bp - bp.mean()
+        rr = torch.linalg.qr(torch.cat((wc, bc[:, None]), 1), mode="r").R          # [C + 1, C + 1]: |Wc t + bc|^2 = |R [t; 1]|^2
+        r_bf = ops.cast(rr[:C, :C].float().contiguous(), split)
+        r0 = rr[:C, C].float().contiguous()
+        c0 = float(rr[C, C] ** 2)
+        gam, bet = f64(self.norm_tokens.weight), self.norm_tokens.bias.detach().float().view(1, d).contiguous()
+        a_pe = ops.cast(ops.scale_add_rows(self._pe_tiled(H, W, dev), bet), split)  # beta + PE[key], the A operand of the table GEMM
+        layers = []
+        for blk in self.blocks:
+            blk.precision = self.precision
+            wkv = f64(blk.ca.in_proj_weight)[d:]
+            m_bf = ops.cast((wkv @ (gam[:, None] * wc)).float().contiguous(), split)
+            m0 = (wkv @ (gam * bc)).float().contiguous()
+            t_tab, _ = ops.linear(a_pe, blk._w(blk.ca.in_proj_weight), blk.ca.in_proj_bias, out_f32=True, w_rows=(d, 3 * d))
+            layers.append((m_bf, m0, t_tab))
+        fold = (r_bf, r0, c0, layers)
+        self._pe_cache[key] = (ver, fold)
+        return fold
+
+    def _tile_kv(self, li: int, feat, idx, live, dirty, counts, cap_rows, batch, H, W, out) -> None:
+        C = feat.shape[1]
+        r_bf, r0, c0, layers = self._kv_fold(C, H, W, feat.device)
+        m_bf, m0, t_tab = layers[li]
+        ops.bev_tile_kv(feat, idx, live, dirty, counts, cap_rows, batch, H, W, self.refine[0].weight.detach().reshape(C, 9).contiguous(),
+                        self.refine[0].bias, m_bf, m0, r_bf, r0, c0, self.d_model, self.norm_tokens.eps, t_tab, out, tag="bev_kv")
+
     def _kv_buffers(self, C: int, H: int, W: int, dev, batch: int) -> List[torch.Tensor]:
         """Per layer ONE K|V buffer [HW + batch*HW, 2d] bf16.  Rows 0 .. HW-1: the per-model TABLE = K|V of the EMPTY scene by the same
-        kernels that serve the dirty rows (every cell forced dirty; key order = tile-major), cached per weights version and precision
+        kernel that serves the dirty rows (every cell forced dirty; key order = tile-major), cached per weights version and precision
         mode -- input-independent like the positional table.  Rows HW ..: the step's computed rows (capacity for `batch` scenes)."""
         params = [self.refine[0].weight, self.refine[0].bias, self.proj.weight, self.proj.bias, self.norm_tokens.weight, self.norm_tokens.bias,
                   self.geo_mlp[0].weight, self.geo_mlp[0].bias, self.geo_mlp[2].weight, self.geo_mlp[2].bias, self.view_embed]
         for blk in self.blocks:
             params += [blk.ca.in_proj_weight, blk.ca.in_proj_bias]
-        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(),)
+        fused = not os.environ.get("LVQ_NO_FUSED_KV")
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(), fused)
         key = ("kv_buffer", H, W, dev)
         hw, d = H * W, self.d_model
         rows = hw + batch * hw
@@ -367,12 +415,15 @@ class VATLiDAR(_HipModule):
         idx = torch.full((1, H, W), -1, dtype=torch.int32, device=dev)
         live, dirty, src, counts = ops.bev_tiles(idx, 1, H, W, dev, 0, force_all=True)
         feat = torch.zeros((1, C), dtype=torch.float32, device=dev)
-        x = self._tile_tokens(feat, idx, live, dirty, counts, hw, 1, H, W)
+        x = None if fused else self._tile_tokens(feat, idx, live, dirty, counts, hw, 1, H, W)
         bufs = []
-        for blk in self.blocks:
+        for li, blk in enumerate(self.blocks):
             blk.precision = self.precision
             buf = torch.empty((rows, 2 * d), dtype=torch.bfloat16, device=dev)
-            ops.linear_live_rows(x, blk._w(blk.ca.in_proj_weight), blk.ca.in_proj_bias, counts[2:], (d, 3 * d), out=buf[:hw])
+            if fused:
+                self._tile_kv(li, feat, idx, live, dirty, counts, hw, 1, H, W, buf[:hw])
+            else:
+                ops.linear_live_rows(x, blk._w(blk.ca.in_proj_weight), blk.ca.in_proj_bias, counts[2:], (d, 3 * d), out=buf[:hw])
             bufs.append(buf)
         self._pe_cache[key] = (ver, bufs)
         return bufs
@@ -411,11 +462,14 @@ class VATLiDAR(_HipModule):
         kvs = self._kv_buffers(C, H, W, dev, batch)
         idx = ops.pillar_index_map(coords_bzyx, n_live, batch, H, W)
         live, dirty, src, counts = ops.bev_tiles(idx, batch, H, W, dev, H * W, force_all=all_tiles_live)
-        x_live = self._tile_tokens(feat, idx, live, dirty, counts, batch * nt * 64, batch, H, W)
+        fused = not os.environ.get("LVQ_NO_FUSED_KV")          # K|V straight from the conv token (k_tile_kv) vs tokens -> K|V GEMM
+        x_live = None if fused else self._tile_tokens(feat, idx, live, dirty, counts, batch * nt * 64, batch, H, W)
         signed = not all_tiles_live and not os.environ.get("LVQ_NO_SIGNED_STREAM")
         q2 = None if signed else self._queries(batch)
         for li, (blk, table) in enumerate(zip(self.blocks, kvs)):
             blk.precision = self.precision
+            if fused:
+                self._tile_kv(li, feat, idx, live, dirty, counts, batch * nt * 64, batch, H, W, table[H * W:])
             if li == 0 and signed:
                 # block 0: the queries are the same for every scene -> query side once, attention over the live pieces only
                 q2_1, qp = blk.shared_query_side(self._queries(1), self.n_queries)

@@ -339,6 +339,34 @@ def test_tiled_route_is_bit_identical_to_all_tiles_live(prec, monkeypatch):
     assert (a["lidar_tokens"] - c["lidar_tokens"]).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("prec", ["bf16", "mixed"])
+def test_fused_kv_kernel_matches_token_kernel_plus_gemm(prec, monkeypatch):
+    """lvq_bev_tile_kv (LayerNorm and the K|V projection folded onto the 64-channel conv token: K|V = rstd (M t + m0) + T[key]) against
+    the unfused pair lvq_bev_tile_tokens -> lvq_gemm_bf16_live_rows on the same scenes: the K|V rows of the dirty cells and of the
+    per-model table agree to the rounding of the bf16 result (the fused form skips the bf16 rounding of the d-wide token), and so do
+    the LiDAR tokens."""
+    cfg = tiled_cfg()
+    pipe = P.FusionPipeline(cfg, DEV, precision=prec)
+    pts, off, patches, _, _ = P.synthetic_batch(cfg, 2, 1001, DEV)
+    h, w = cfg.bev_hw
+    a = pipe(pts, off, patches)
+    vl = pipe.vat_lidar
+    kv_f = [b.clone() for b in vl._pe_cache[("kv_buffer", h, w, torch.device(DEV))][1]]
+    nd = int(vl._last_tile_counts[2])
+    monkeypatch.setenv("LVQ_NO_FUSED_KV", "1")
+    b = pipe(pts, off, patches)
+    kv_u = vl._pe_cache[("kv_buffer", h, w, torch.device(DEV))][1]
+    assert int(vl._last_tile_counts[2]) == nd and 0 < nd < 2 * h * w
+    for f, u in zip(kv_f, kv_u):
+        f32, u32 = f[:h * w + nd].float(), u[:h * w + nd].float()
+        scale = float(u32.abs().max())
+        # bf16 results of two different roundings of the same number differ by at most one ulp (2^-8 relative) + the token rounding of the unfused route
+        assert float((f32 - u32).abs().max()) < (2.0 ** -6 if prec == "bf16" else 2.0 ** -7) * scale
+        assert float((f32 - u32).abs().mean()) < 2.0 ** -10 * scale
+    tol = 5e-2 if prec == "bf16" else 5e-4
+    assert float((a["lidar_tokens"] - b["lidar_tokens"]).abs().max()) < tol
+
+
 @pytest.mark.parametrize("prec,tol", [("mixed", 2e-3), ("bf16", None)])
 def test_tiled_route_vs_oracle(prec, tol):
     """Small-grid pipeline through the tiled route against the CPU oracle.  16 384 keys average the per-key roundings 4x less
