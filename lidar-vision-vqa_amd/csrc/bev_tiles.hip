@@ -769,39 +769,41 @@ __global__ void __launch_bounds__(512) k_tile_kv(KvArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's halo DMA (next group) has landed
         __syncthreads();                                          // B2: partial sums complete; every wave's DMA landed; codes of this group read
         store_idx(idxh + (it & 1) * 256, i2, c2);
-        if (has_nx) conv_tile(ih_nx, buf ^ 1);
-        // ---- product, rescale, + table, store ----
+        // ---- product, rescale, + table, store.  The table rows (T[key], 2 x 4 J bytes per lane and 16-cell group) and the piece's dirty
+        // word are requested ONE 16-cell group ahead: group 0's before the conv of the next work item, group q + 1's before group q's
+        // MFMAs -- with the requests issued where they were used, the four round trips per work item were the kernel's critical path
         {
             const float *pr = part + buf * 4 * TCELLS;
-#pragma unroll 1
-            for (int gq = 0; gq < 4; ++gq) {
-                const int cell = gq * 16 + l15;
-                const int code = gq == 0 ? code_cur[0] : gq == 1 ? code_cur[1] : gq == 2 ? code_cur[2] : code_cur[3];
+            auto cell_of = [&](int gq) { return gq * 16 + l15; };
+            auto code_of = [&](int gq) { return gq == 0 ? code_cur[0] : gq == 1 ? code_cur[1] : gq == 2 ? code_cur[2] : code_cur[3]; };
+            auto request = [&](int gq, f32x4 (&te)[2 * JH], int2 &pd) {
+                const int cell = cell_of(gq), code = code_of(gq);
                 const bool in_list = code >= 0;
                 const int64_t prow = in_list ? (int64_t)((code >> 3) / a.S) * TCELLS + (code & 7) * PCELLS + (cell & 7) : 0;
-                const int2 pd = in_list ? a.piece_dirty[g * NPIECE + (cell >> 3)] : make_int2(0, 0);
+                pd = in_list ? a.piece_dirty[g * NPIECE + (cell >> 3)] : make_int2(0, 0);
+                const float *tep = a.te + prow * (2 * N) + ncol0 + col0;
+#pragma unroll
+                for (int jj = 0; jj < 2 * JH; ++jj) te[jj] = *reinterpret_cast<const f32x4 *>(tep + 4 * jj);
+            };
+            auto emit = [&](int gq, const f32x4 (&te)[2 * JH], const int2 pd) {
+                const int cell = cell_of(gq);
                 const bool valid = (pd.y >> (cell & 7)) & 1;
                 const int64_t orow = pd.x + __popc((unsigned)pd.y & ((1u << (cell & 7)) - 1u));
-                const float *tep = a.te + prow * (2 * N) + ncol0 + col0;
-                f32x4 te0[JH], te1[JH];
-#pragma unroll
-                for (int jj = 0; jj < JH; ++jj) te0[jj] = *reinterpret_cast<const f32x4 *>(tep + 4 * jj);
-#pragma unroll
-                for (int jj = 0; jj < JH; ++jj) te1[jj] = *reinterpret_cast<const f32x4 *>(tep + 4 * (JH + jj));
                 const float ss = (pr[cell] + pr[TCELLS + cell]) + (pr[2 * TCELLS + cell] + pr[3 * TCELLS + cell]) + a.c0;
                 const float rstd = 1.0f / sqrtf(ss * a.inv_d + a.eps);
                 bf16x8 th0, th1, tl0, tl1;
                 load_t(buf, gq, th0, th1, tl0, tl1);
                 uint16_t *dst = a.out + orow * (2 * N) + ncol0 + col0;
-                auto half_out = [&](auto hf_tag, const f32x4 (&te)[JH]) {
+                auto half_out = [&](auto hf_tag) {
                     constexpr int HF = decltype(hf_tag)::value;
                     f32x4 acc[JH];
                     product(hf_tag, th0, th1, tl0, tl1, acc);
                     uint32_t oh[2 * JH];
 #pragma unroll
                     for (int jj = 0; jj < JH; ++jj) {
-                        oh[2 * jj] = pack_bf16(acc[jj][0] * rstd + te[jj][0], acc[jj][1] * rstd + te[jj][1]);
-                        oh[2 * jj + 1] = pack_bf16(acc[jj][2] * rstd + te[jj][2], acc[jj][3] * rstd + te[jj][3]);
+                        const f32x4 tv = te[HF * JH + jj];
+                        oh[2 * jj] = pack_bf16(acc[jj][0] * rstd + tv[0], acc[jj][1] * rstd + tv[1]);
+                        oh[2 * jj + 1] = pack_bf16(acc[jj][2] * rstd + tv[2], acc[jj][3] * rstd + tv[3]);
                     }
                     if (valid) {
 #pragma unroll
@@ -809,9 +811,20 @@ __global__ void __launch_bounds__(512) k_tile_kv(KvArgs a) {
                             *reinterpret_cast<uint2 *>(dst + 2 * (2 * HF * JH + q)) = make_uint2(oh[q], oh[q + 1]);
                     }
                 };
-                half_out(std::integral_constant<int, 0>{}, te0);
-                half_out(std::integral_constant<int, 1>{}, te1);
-            }
+                half_out(std::integral_constant<int, 0>{});
+                half_out(std::integral_constant<int, 1>{});
+            };
+            f32x4 te_a[2 * JH], te_b[2 * JH];
+            int2 pd_a, pd_b;
+            request(0, te_a, pd_a);
+            if (has_nx) conv_tile(ih_nx, buf ^ 1);
+            request(1, te_b, pd_b);
+            emit(0, te_a, pd_a);
+            request(2, te_a, pd_a);
+            emit(1, te_b, pd_b);
+            request(3, te_b, pd_b);
+            emit(2, te_a, pd_a);
+            emit(3, te_b, pd_b);
         }
         buf ^= 1;
     }
