@@ -294,6 +294,20 @@ def main():
                          "traffic": tr, "traffic_source": src, "avg_launch_ms": round(at_ms, 4), "flops_per_launch": at_flops * ex,
                          "keys_streamed": keys_streamed, "keys_dense": S * h * w,
                          "dense_formula_flops": at_flops, "dense_formula_rate": round(ach, 2), "dense_formula_frac": round(ach / PEAK_BF16_TFLOPS, 4)}
+    # the fused K|V kernel (default route): refine conv + folded LayerNorm / K|V projection for the dirty cells, HBM-side kernel
+    roofline_bev_kv = None
+    bk_ms = avg_ms(events.get("bev_kv", []))
+    if bk_ms:
+        nbytes = live_rows * (2 * 2 * d) + (h * w) * (2 * d) * 4 + S * h * w * 4      # K|V rows out (bf16) + the table T once (fp32) + index map
+        ex_flops = 2.0 * live_rows * (2 * d + 64) * 64 * {"bf16": 1, "mixed": 3, "bf16x3": 3}[prec]
+        tr, src = profile_traffic([f"k_tile_kv S={S} {prec}"])
+        roofline_bev_kv = {"bound": "hbm", "kernel": "k_tile_kv (pillar halo gather + depthwise 3x3 + GELU -> 64-channel token t -> K|V = rstd (M t + m0) + T[key] "
+                           f"for the {live_rows} dirty cells of {S * h * w}; LayerNorm and the 768-deep K|V projection folded into a 64-deep one)",
+                           "achieved": round(nbytes / (bk_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": round(nbytes / (bk_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": nbytes, "traffic": tr, "traffic_source": src,
+                           "avg_launch_ms": round(bk_ms, 4), "rows": live_rows, "rows_dense": S * h * w,
+                           "mfma_flops_executed": ex_flops, "mfma_rate": round(ex_flops / (bk_ms * 1e-3) / 1e12, 1),
+                           "replaces": "token kernel + K|V GEMM over the dirty rows (4 d^2 FLOPs per key, SURVEY 8d): 4.1 + 10.0 ms at the same row count"}
     if roofline_kv or roofline_attn:
         roofline = roofline_attn if (at_ms or 0) >= (kv_ms or 0) else roofline_kv
 
@@ -305,7 +319,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: " + cfg.describe(), "scenes_per_gpu_per_step": S,
                    "fused_tokens_per_scene": cfg.n_queries, "parallelism": f"scene-parallel x{world}",
                    "precision_mode": args.precision + " (bf16 MFMA tiles throughout; see parity_vs_cpu for the error of every mode)"},
-        "roofline": roofline, "roofline_kv_proj": roofline_kv, "roofline_attention": roofline_attn,
+        "roofline": roofline, "roofline_kv_proj": roofline_kv, "roofline_bev_kv": roofline_bev_kv, "roofline_attention": roofline_attn,
     }
 
     mode_values = {args.precision: round(value, 1)}

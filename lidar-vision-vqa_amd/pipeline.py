@@ -56,7 +56,7 @@ class PipelineConfig:
         h, w = self.bev_hw
         return (f"{self.n_points}-pt scenes (Dist-{self.dist}) -> hard voxelise {self.voxel_3d} T={self.t_3d} max={self.max_voxels_3d} + MeanVFE; "
                 f"pillars {self.voxel_pillar} T={self.t_pillar} max={self.max_pillars} -> PillarVFE{self.pillar_filters} -> "
-                f"PointPillarScatter {h}x{w} (as an index map; tiled key stream: tokens and K|V computed for the 2x4-cell pieces (8 keys) with a pillar in their halo, the rest from the per-model table; bit-identical to computing every cell) -> VATLiDAR(c_in={self.pillar_filters[-1]},d={self.d_model},nq={self.n_queries},"
+                f"PointPillarScatter {h}x{w} (as an index map; sparse key stream: K|V computed only for the cells with a pillar in their 3x3 neighbourhood, by LayerNorm and the K|V projection folded onto the 64-channel conv token, every other key from the per-model table; block 0 attends to the computed rows only, signed against the table's softmax totals) -> VATLiDAR(c_in={self.pillar_filters[-1]},d={self.d_model},nq={self.n_queries},"
                 f"L={self.n_layers},h={self.n_heads}) -> VATBlock(q=LiDAR tokens, kv={self.n_patches} ViT-B/16 patches)")
 
 
