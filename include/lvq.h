@@ -250,11 +250,14 @@ int lvq_bev_tile_tokens(const float *pillar_feat, const int32_t *idx_map, const 
  * with M = W_kv diag(gamma) Wc [2 n, 64], m0 = W_kv (gamma * bc) [2 n], T[key] = W_kv (beta + PE[key]) + b_kv [ny*nx (tile-major), 2 n] fp32,
  * (Wc, bc) = (Wp, bp) minus their means over the d_ln outputs, R [64, 64] the triangular factor of [Wc bc] (c0 = its corner squared):
  * vat_lidar.py:222-248 + vat_blocks.py:42 folded once per weights version (exact algebra; the 768-deep projection becomes 64-deep).
- * m_lo / r_lo != NULL: t, M and R as hi + lo (three products).  kv [dirty rows, 2 n] bf16: the compact rows numbered by lvq_bev_tiles. */
+ * m_lo / r_lo != NULL: t, M and R as hi + lo (three products).  kv [dirty rows, 2 n] bf16: the compact rows numbered by lvq_bev_tiles.
+ * ws != NULL (lvq_bev_tile_kv_workspace_bytes(cap_tiles)): two launches -- k_conv_rows stores (t, rstd, key) of the dirty rows, k_kv_rows
+ * projects contiguous 64-row tiles -- instead of the single kernel; the same arithmetic, bit-identical rows. */
+size_t lvq_bev_tile_kv_workspace_bytes(int64_t cap_tiles);
 int lvq_bev_tile_kv(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *piece_dirty,
                     const int32_t *counts, int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9,
                     const lvq_bf16 *m, const lvq_bf16 *m_lo, const float *m0, const lvq_bf16 *r, const lvq_bf16 *r_lo, const float *r0, float c0,
-                    int d_ln, float eps, const float *t_tiled, int n, lvq_bf16 *kv, lvq_stream_t stream);
+                    int d_ln, float eps, const float *t_tiled, int n, lvq_bf16 *kv, void *ws, size_t ws_bytes, lvq_stream_t stream);
 /* c[0 .. *m_rows_dev) = a @ w^T + bias over the live rows only (the row count stays on the device); m_cap, n multiples of 256,
  * k of 64.  Operand forms as lvq_gemm_bf16 (plain | a plain, w hi + lo | both hi + lo). */
 int lvq_gemm_bf16_live_rows(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,

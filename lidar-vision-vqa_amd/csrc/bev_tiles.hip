@@ -830,6 +830,368 @@ __global__ void __launch_bounds__(512) k_tile_kv(KvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The same computation as k_tile_kv in two launches (the default): k_conv_rows produces, per DIRTY cell and in compact row order, the
+// conv token t (bf16 hi + lo, 256 B), rstd and the cell's key; k_kv_rows is then a plain 64-deep projection over contiguous 64-row
+// tiles -- no halo round trip, no conv, no statistics pass and no dirty masks in the MFMA kernel, one barrier per tile, and the conv
+// runs once instead of once per column half.  (k_tile_kv: 5.7 ms per 32 scenes, 51 % of its wave cycles waiting.)
+// ---------------------------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float *feat;            // [M, 64] pillar features
+    const int32_t *idx;           // [S, H, W] pillar row or -1
+    const int32_t *live_list;     // flat piece indices (t * S + s) * 8 + p
+    const int2 *piece_dirty;      // per live piece: (first dirty-row number, dirty mask)
+    const int32_t *counts;        // counts[0] = live pieces
+    const float *w9, *b9;         // depthwise conv [64, 9], [64]
+    const uint16_t *rh, *rl;      // R [64, 64] bf16 hi / lo (rl may be null: plain operands)
+    const float *r0;              // [64]
+    float c0, inv_d, eps;
+    int S, H, W;
+    uint16_t *th, *tl;            // out: t rows [dirty rows, 64] bf16 hi / lo (tl null: plain)
+    float *rstd;                  // out: [dirty rows]
+    int32_t *key;                 // out: [dirty rows] the cell's row in the table T (tile-major key index)
+};
+
+template <bool X3>
+__global__ void __launch_bounds__(512) k_conv_rows(ConvArgs a) {
+    constexpr int C = 64, NWV = 8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *t_hi = reinterpret_cast<uint16_t *>(smem);                      // [2][64][64] bf16, chunk-swizzled (B operand of the R tiles)
+    uint16_t *t_lo = t_hi + 2 * TCELLS * C;
+    float *halo = reinterpret_cast<float *>(t_lo + 2 * TCELLS * C);           // [192][64] fp32
+    int32_t *idxh = reinterpret_cast<int32_t *>(halo + NSLOT * C);            // [2][256]
+    float *part = reinterpret_cast<float *>(idxh + 2 * 256);                  // [2][4][64]
+    float *w9s = part + 2 * 4 * TCELLS;                                       // [9][64]
+    float *b9s = w9s + 9 * C;
+    float *r0s = b9s + C;
+    uint16_t *r_hi = reinterpret_cast<uint16_t *>(r0s + C);                   // [64][64]
+    uint16_t *r_lo = r_hi + C * C;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const int tw = a.W / TS;
+    const int n_live = a.counts[0];
+    const int64_t n_groups = ((int64_t)n_live + NPIECE - 1) / NPIECE;
+    const int64_t g_begin = blockIdx.x, g_end = n_groups, g_step = gridDim.x;
+
+    for (int e = tid; e < 9 * C; e += 512) w9s[e] = a.w9[(e % C) * 9 + e / C];
+    if (tid < C) { b9s[tid] = a.b9 ? a.b9[tid] : 0.f; r0s[tid] = a.r0[tid]; }
+    for (int e = tid; e < C * C / 8; e += 512) {
+        reinterpret_cast<u32x4 *>(r_hi)[e] = reinterpret_cast<const u32x4 *>(a.rh)[e];
+        if (X3) reinterpret_cast<u32x4 *>(r_lo)[e] = reinterpret_cast<const u32x4 *>(a.rl)[e];
+    }
+    auto load_idx = [&](int64_t g, int &code_out) -> int {
+        code_out = -1;
+        if (tid >= NSLOT) return -1;
+        const int j = tid / PHALO, hc = tid - j * PHALO;
+        const int64_t k = g * NPIECE + j;
+        if (k >= n_live) return -1;
+        const int code = a.live_list[k];
+        code_out = code;
+        const int p = code & 7, ts = code >> 3, t = ts / a.S, sc = ts - t * a.S;
+        int y0, x0;
+        piece_origin(t, p, tw, y0, x0);
+        const int gy = y0 - 1 + hc / PW, gx = x0 - 1 + hc % PW;
+        return (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? a.idx[((int64_t)sc * a.H + gy) * a.W + gx] : -1;
+    };
+    auto store_idx = [&](int32_t *ih, int v, int code) {
+        if (tid < NSLOT) {
+            ih[tid] = v;
+            if (tid % PHALO == 0) ih[200 + tid / PHALO] = code;
+        }
+    };
+    auto dma_halo = [&](const int32_t *ih) {
+        for (int q = wid; q < NSLOT / 4; q += NWV) {
+            const int slot = q * 4 + (lane >> 4);
+            const int row = ih[slot];
+            if (row >= 0)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.feat + (int64_t)row * C + 4 * l15),
+                                                 (__attribute__((address_space(3))) void *)(halo + q * 4 * C), 16, 0, 0);
+        }
+    };
+    // depthwise 3x3 + GELU (the tap order and fmaf chain of k_dwconv3x3_gelu); the dirty cells' tokens also leave for HBM right here
+    auto conv_tile = [&](const int32_t *ih, int buf, int64_t g) {
+        const int cell = tid >> 3, cg = (tid & 7) * 8, hb = (cell >> 3) * PHALO, cy = (cell >> 2) & 1, cx = cell & 3;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = b9s[cg + c];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int slot = hb + (cy + rr) * PW + cx + k;
+                if (ih[slot] >= 0) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(halo + slot * C + cg), v1 = *reinterpret_cast<const f32x4 *>(halo + slot * C + cg + 4);
+                    const f32x4 k0 = *reinterpret_cast<const f32x4 *>(w9s + (rr * 3 + k) * C + cg), k1 = *reinterpret_cast<const f32x4 *>(w9s + (rr * 3 + k) * C + cg + 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { acc[c] = fmaf(v0[c], k0[c], acc[c]); acc[4 + c] = fmaf(v1[c], k1[c], acc[4 + c]); }
+                }
+            }
+        uint32_t hi[4], lo[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float y0 = gelu_erf(acc[2 * c]), y1 = gelu_erf(acc[2 * c + 1]);
+            hi[c] = pack_bf16(y0, y1);
+            lo[c] = pack_bf16(y0 - __uint_as_float(hi[c] << 16), y1 - __uint_as_float(hi[c] & 0xffff0000u));
+        }
+        const int ch = (tid & 7) ^ ((cell >> 1) & 7);
+        *reinterpret_cast<u32x4 *>(t_hi + (buf * TCELLS + cell) * C + ch * 8) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+        if (X3) *reinterpret_cast<u32x4 *>(t_lo + (buf * TCELLS + cell) * C + ch * 8) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+        const int code = ih[200 + (cell >> 3)];
+        if (code >= 0) {
+            const int2 pd = a.piece_dirty[g * NPIECE + (cell >> 3)];
+            if ((pd.y >> (cell & 7)) & 1) {
+                const int64_t orow = pd.x + __popc((unsigned)pd.y & ((1u << (cell & 7)) - 1u));
+                *reinterpret_cast<u32x4 *>(a.th + orow * C + cg) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+                if (X3) *reinterpret_cast<u32x4 *>(a.tl + orow * C + cg) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+            }
+        }
+    };
+    auto load_t = [&](int buf, int gq, bf16x8 &th0, bf16x8 &th1, bf16x8 &tl0, bf16x8 &tl1) {
+        const int row = gq * 16 + l15;
+        const int c0 = (g4 ^ ((row >> 1) & 7)) * 8, c1 = ((4 + g4) ^ ((row >> 1) & 7)) * 8;
+        th0 = *reinterpret_cast<const bf16x8 *>(t_hi + (buf * TCELLS + row) * C + c0);
+        th1 = *reinterpret_cast<const bf16x8 *>(t_hi + (buf * TCELLS + row) * C + c1);
+        if (X3) {
+            tl0 = *reinterpret_cast<const bf16x8 *>(t_lo + (buf * TCELLS + row) * C + c0);
+            tl1 = *reinterpret_cast<const bf16x8 *>(t_lo + (buf * TCELLS + row) * C + c1);
+        }
+    };
+
+    if (tid < 256) { idxh[tid] = -1; idxh[256 + tid] = -1; }
+    __syncthreads();
+    if (g_begin >= g_end) return;
+    {
+        int c0, c1;
+        const int i0 = load_idx(g_begin, c0);
+        const int i1 = g_begin + g_step < g_end ? load_idx(g_begin + g_step, c1) : (c1 = -1, -1);
+        store_idx(idxh, i0, c0);
+        store_idx(idxh + 256, i1, c1);
+    }
+    __syncthreads();
+    dma_halo(idxh);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    conv_tile(idxh, 0, g_begin);
+    int buf = 0;
+    for (int64_t g = g_begin, it = 0; g < g_end; g += g_step, ++it) {
+        __syncthreads();                                          // B1: t[buf] complete, halo buffer free, part[buf] free
+        const int32_t *ih_cur = idxh + (it & 1) * 256, *ih_nx = idxh + ((it + 1) & 1) * 256;
+        const bool has_nx = g + g_step < g_end, has_n2 = g + 2 * g_step < g_end;
+        if (has_nx) dma_halo(ih_nx);
+        const int my_code = tid < TCELLS ? ih_cur[200 + (tid >> 3)] : -1;     // piece code of cell tid (threads 0..63 finish the rows)
+        int c2 = -1;
+        const int i2 = has_n2 ? load_idx(g + 2 * g_step, c2) : -1;
+        // |R t + r0|^2 per cell: wave w takes the 16-row tile w & 3 of R for the 16-cell groups 2 (w >> 2), 2 (w >> 2) + 1
+        {
+            const int rt = wid & 3;
+            const uint16_t *rp = r_hi + (16 * rt + l15) * C + 8 * g4, *rpl = r_lo + (16 * rt + l15) * C + 8 * g4;
+            const bf16x8 ra0 = *reinterpret_cast<const bf16x8 *>(rp), ra1 = *reinterpret_cast<const bf16x8 *>(rp + 32);
+            bf16x8 rl0 = ra0, rl1 = ra1;
+            if (X3) { rl0 = *reinterpret_cast<const bf16x8 *>(rpl); rl1 = *reinterpret_cast<const bf16x8 *>(rpl + 32); }
+            const f32x4 rinit = *reinterpret_cast<const f32x4 *>(r0s + 16 * rt + 4 * g4);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int gq = 2 * (wid >> 2) + u;
+                bf16x8 th0, th1, tl0, tl1;
+                load_t(buf, gq, th0, th1, tl0, tl1);
+                f32x4 v = rinit;
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra0, th0, v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra1, th1, v, 0, 0, 0);
+                if (X3) {
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra0, tl0, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ra1, tl1, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl0, th0, v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl1, th1, v, 0, 0, 0);
+                }
+                float sq = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                sq += __shfl_xor(sq, 16);
+                sq += __shfl_xor(sq, 32);
+                if (g4 == 0) part[(buf * 4 + rt) * TCELLS + gq * 16 + l15] = sq;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's halo DMA (next group) has landed
+        __syncthreads();                                          // B2: partial sums complete; every wave's DMA landed; codes of this group read
+        store_idx(idxh + (it & 1) * 256, i2, c2);
+        if (tid < TCELLS && my_code >= 0) {                        // rstd and key of this group's dirty cells
+            const int cell = tid;
+            const int2 pd = a.piece_dirty[g * NPIECE + (cell >> 3)];
+            if ((pd.y >> (cell & 7)) & 1) {
+                const int64_t orow = pd.x + __popc((unsigned)pd.y & ((1u << (cell & 7)) - 1u));
+                const float *pr = part + buf * 4 * TCELLS;
+                const float ss = (pr[cell] + pr[TCELLS + cell]) + (pr[2 * TCELLS + cell] + pr[3 * TCELLS + cell]) + a.c0;
+                a.rstd[orow] = 1.0f / sqrtf(ss * a.inv_d + a.eps);
+                a.key[orow] = ((my_code >> 3) / a.S) * TCELLS + (my_code & 7) * PCELLS + (cell & 7);
+            }
+        }
+        if (has_nx) conv_tile(ih_nx, buf ^ 1, g + g_step);
+        buf ^= 1;
+    }
+}
+
+struct KvRowArgs {
+    const uint16_t *th, *tl;      // t rows [n, 64] bf16 hi / lo
+    const float *rstd;            // [n]
+    const int32_t *key;           // [n]
+    const int32_t *n_rows;        // device-side row count
+    const uint16_t *mh, *ml;      // M [2 N, 64] bf16 hi / lo
+    const float *m0;              // [2 N]
+    const float *te;              // T [keys, 2 N] fp32
+    uint16_t *out;                // K|V rows [n, 2 N] bf16
+};
+
+template <int J, bool X3>
+__global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
+    constexpr int N = 128 * J, C = 64, JH = J / 2;
+    static_assert(J % 2 == 0, "even J");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *t_hi = reinterpret_cast<uint16_t *>(smem);                      // [2][64][64] bf16, chunk-swizzled, filled by LDS-DMA
+    uint16_t *t_lo = t_hi + 2 * TCELLS * C;
+    float *pbias = reinterpret_cast<float *>(t_lo + 2 * TCELLS * C);          // [N] m0 of this half
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
+    const int64_t n_rows = *a.n_rows;
+    const int64_t n_groups = (n_rows + TCELLS - 1) / TCELLS;
+    // each XCD one contiguous eighth of the rows (they are in (tile, scene) order: neighbouring tiles share rows of T), its
+    // workgroups interleaved; the two column halves of a tile run on the same XCD
+    const bool x8 = gridDim.x >= 16 && gridDim.x % 16 == 0;
+    const int nxcd = x8 ? 8 : 1;
+    const int xcd = x8 ? (int)blockIdx.x & 7 : 0;
+    const int half = x8 ? ((int)blockIdx.x >> 3) & 1 : (int)blockIdx.x & 1;
+    const int wg_r = x8 ? (int)blockIdx.x >> 4 : (int)blockIdx.x >> 1, wg_R = x8 ? (int)gridDim.x >> 4 : ((int)gridDim.x + 1) >> 1;
+    const int64_t per_x = (n_groups + nxcd - 1) / nxcd;
+    const int64_t x_begin = (int64_t)xcd * per_x, x_end = x_begin + per_x < n_groups ? x_begin + per_x : n_groups;
+    const int64_t g_begin = x_begin + wg_r, g_end = x_end, g_step = wg_R;
+    const int ncol0 = half * N;
+    for (int e = tid; e < N; e += 512) pbias[e] = a.m0[ncol0 + e];
+
+    bf16x8 wf[J][2], wfl[X3 ? J : 1][2];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int n = ncol0 + 16 * J * wid + 16 * j + l15;            // column tile j of this wave, A row m = l15 -> column 16 j + m
+        wf[j][0] = *reinterpret_cast<const bf16x8 *>(a.mh + (int64_t)n * C + 8 * g4);
+        wf[j][1] = *reinterpret_cast<const bf16x8 *>(a.mh + (int64_t)n * C + 32 + 8 * g4);
+        if (X3) {
+            wfl[j][0] = *reinterpret_cast<const bf16x8 *>(a.ml + (int64_t)n * C + 8 * g4);
+            wfl[j][1] = *reinterpret_cast<const bf16x8 *>(a.ml + (int64_t)n * C + 32 + 8 * g4);
+        }
+    }
+    // C layout: lane (cell = l15, g4) holds rows 4 g4 .. 4 g4 + 3 of every column tile, i.e. columns 16 J w + 16 j + 4 g4 + r: for a
+    // fixed j the four g4 lanes of a cell cover 64 CONTIGUOUS bytes of its T row (one full line per cell and request; with 4 J
+    // consecutive columns per lane every request touched 64 different lines for 16 bytes each: 5.50 -> 5.17 ms)
+    const int col0 = 16 * J * wid + 4 * g4;
+    // stage the 64 contiguous t rows of tile g: wave w moves rows 8 w .. 8 w + 7 (one 1-KiB LDS-DMA for hi, one for lo); LDS position
+    // (row, chunk c) receives SOURCE chunk c ^ ((row >> 1) & 7), the swizzle the fragment reads expect.  Rows past the end are clamped.
+    auto stage = [&](int64_t g, int buf) {
+        const int row = 8 * wid + (lane >> 3), c = lane & 7;
+        int64_t r = g * TCELLS + row;
+        r = r < n_rows ? r : n_rows - 1;
+        const int64_t so = r * C + ((c ^ ((row >> 1) & 7)) << 3);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.th + so),
+                                         (__attribute__((address_space(3))) void *)(t_hi + (buf * TCELLS + 8 * wid) * C), 16, 0, 0);
+        if (X3)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(a.tl + so),
+                                             (__attribute__((address_space(3))) void *)(t_lo + (buf * TCELLS + 8 * wid) * C), 16, 0, 0);
+    };
+    auto load_t = [&](int buf, int gq, bf16x8 &th0, bf16x8 &th1, bf16x8 &tl0, bf16x8 &tl1) {
+        const int row = gq * 16 + l15;
+        const int c0 = (g4 ^ ((row >> 1) & 7)) * 8, c1 = ((4 + g4) ^ ((row >> 1) & 7)) * 8;
+        th0 = *reinterpret_cast<const bf16x8 *>(t_hi + (buf * TCELLS + row) * C + c0);
+        th1 = *reinterpret_cast<const bf16x8 *>(t_hi + (buf * TCELLS + row) * C + c1);
+        if (X3) {
+            tl0 = *reinterpret_cast<const bf16x8 *>(t_lo + (buf * TCELLS + row) * C + c0);
+            tl1 = *reinterpret_cast<const bf16x8 *>(t_lo + (buf * TCELLS + row) * C + c1);
+        }
+    };
+    auto opaque = [](const float *p) { asm volatile("" : "+v"(p)); return p; };
+    auto product = [&](auto hf_tag, const bf16x8 &th0, const bf16x8 &th1, const bf16x8 &tl0, const bf16x8 &tl1, f32x4 (&acc)[JH]) {
+        constexpr int HF = decltype(hf_tag)::value;
+        const float *pb = opaque(pbias + col0);
+#pragma unroll
+        for (int jj = 0; jj < JH; ++jj) {
+            const int j = HF * JH + jj;
+            acc[jj] = *reinterpret_cast<const f32x4 *>(pb + 16 * j);
+            acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], th0, acc[jj], 0, 0, 0);
+            acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], th1, acc[jj], 0, 0, 0);
+            if (X3) {
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], tl0, acc[jj], 0, 0, 0);
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], tl1, acc[jj], 0, 0, 0);
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfl[j][0], th0, acc[jj], 0, 0, 0);
+                acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfl[j][1], th1, acc[jj], 0, 0, 0);
+            }
+        }
+    };
+    if (g_begin >= g_end) return;
+    // the lane's four rows of a tile (row 16 q + l15): key and rstd, fetched a whole tile ahead so that the T requests never wait on them
+    auto load_meta = [&](int64_t g, int (&kq)[4], float (&rq)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int64_t r = g * TCELLS + q * 16 + l15;
+            r = r < n_rows ? r : n_rows - 1;
+            kq[q] = a.key[r];
+            rq[q] = a.rstd[r];
+        }
+    };
+    int kq[4];
+    float rq[4];
+    load_meta(g_begin, kq, rq);
+    stage(g_begin, 0);
+    int buf = 0;
+    for (int64_t g = g_begin; g < g_end; g += g_step) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's rows of tile g have landed (requested a whole tile ago)
+        __syncthreads();                                          // tile g complete for everyone; everyone is done reading the other buffer
+        const bool has_nx = g + g_step < g_end;
+        if (has_nx) stage(g + g_step, buf ^ 1);
+        int kn[4] = {0, 0, 0, 0};
+        float rn[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has_nx) load_meta(g + g_step, kn, rn);
+        // the rows of T are requested one 16-row group ahead of their use
+        auto request = [&](int gq, f32x4 (&te)[2 * JH], float &rs, bool &valid) {
+            valid = g * TCELLS + gq * 16 + l15 < n_rows;
+            rs = gq == 0 ? rq[0] : gq == 1 ? rq[1] : gq == 2 ? rq[2] : rq[3];
+            const int key = gq == 0 ? kq[0] : gq == 1 ? kq[1] : gq == 2 ? kq[2] : kq[3];
+            const float *tep = a.te + (int64_t)key * (2 * N) + ncol0 + col0;
+#pragma unroll
+            for (int jj = 0; jj < 2 * JH; ++jj) te[jj] = *reinterpret_cast<const f32x4 *>(tep + 16 * jj);
+        };
+        auto emit = [&](int gq, const f32x4 (&te)[2 * JH], const float rs, const bool valid) {
+            bf16x8 th0, th1, tl0, tl1;
+            load_t(buf, gq, th0, th1, tl0, tl1);
+            uint16_t *dst = a.out + (g * TCELLS + gq * 16 + l15) * (2 * N) + ncol0 + col0;
+            auto half_out = [&](auto hf_tag) {
+                constexpr int HF = decltype(hf_tag)::value;
+                f32x4 acc[JH];
+                product(hf_tag, th0, th1, tl0, tl1, acc);
+                uint32_t oh[2 * JH];
+#pragma unroll
+                for (int jj = 0; jj < JH; ++jj) {
+                    const f32x4 tv = te[HF * JH + jj];
+                    oh[2 * jj] = pack_bf16(acc[jj][0] * rs + tv[0], acc[jj][1] * rs + tv[1]);
+                    oh[2 * jj + 1] = pack_bf16(acc[jj][2] * rs + tv[2], acc[jj][3] * rs + tv[3]);
+                }
+                if (valid) {
+#pragma unroll
+                    for (int jj = 0; jj < JH; ++jj)
+                        *reinterpret_cast<uint2 *>(dst + 16 * (HF * JH + jj)) = make_uint2(oh[2 * jj], oh[2 * jj + 1]);
+                }
+            };
+            half_out(std::integral_constant<int, 0>{});
+            half_out(std::integral_constant<int, 1>{});
+        };
+        f32x4 te_a[2 * JH], te_b[2 * JH];
+        float rs_a, rs_b;
+        bool va, vb;
+        request(0, te_a, rs_a, va);
+        request(1, te_b, rs_b, vb);
+        emit(0, te_a, rs_a, va);
+        request(2, te_a, rs_a, va);
+        emit(1, te_b, rs_b, vb);
+        request(3, te_b, rs_b, vb);
+        emit(2, te_a, rs_a, va);
+        emit(3, te_b, rs_b, vb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { kq[q] = kn[q]; rq[q] = rn[q]; }
+        buf ^= 1;
+    }
+}
+
 }  // namespace bt
 
 // =================================================================================================
@@ -874,10 +1236,34 @@ template <int J> static int launch_tile_kv(const bt::KvArgs &a, bool x3, int64_t
 
 // K|V rows of the dirty cells straight from the pillar features (k_tile_kv): refine conv + GELU -> t, then
 // kv = rstd (M t + m0) + T[key] with rstd = 1 / sqrt((|R t + r0|^2 + c0) / d_ln + eps).  n = d (the K and the V half are n columns each).
+template <int J> static int launch_kv_rows(const bt::KvRowArgs &a, bool x3, int64_t cap_tiles, hipStream_t st) {
+    const size_t lds = (size_t)2 * 2 * bt::TCELLS * 64 * 2 + (size_t)128 * J * 4;
+    static LvqLdsOnce once;
+    if (lds > 64 * 1024 && !lvq_ensure_lds(once, {(const void *)bt::k_kv_rows<J, false>, (const void *)bt::k_kv_rows<J, true>}, lds)) return LVQ_ELAUNCH;
+    int64_t grid = (int64_t)lvq_cu_count();
+    if (grid > cap_tiles) grid = cap_tiles;
+    grid *= 2;                                                   // two column halves (K, V) per tile
+    if (x3) hipLaunchKernelGGL((bt::k_kv_rows<J, true>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    else    hipLaunchKernelGGL((bt::k_kv_rows<J, false>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    return lvq_launch_status();
+}
+
+// workspace of the two-launch form of lvq_bev_tile_kv: t rows (hi, lo), rstd and key of up to cap_tiles * 64 dirty rows
+extern "C" size_t lvq_bev_tile_kv_workspace_bytes(int64_t cap_tiles) {
+    if (cap_tiles <= 0) return 0;
+    LvqSizer z;
+    z.take<uint16_t>((size_t)cap_tiles * 64 * 64);
+    z.take<uint16_t>((size_t)cap_tiles * 64 * 64);
+    z.take<float>((size_t)cap_tiles * 64);
+    z.take<int32_t>((size_t)cap_tiles * 64);
+    return z.total();
+}
+
 extern "C" int lvq_bev_tile_kv(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *piece_dirty,
                                const int32_t *counts, int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9,
                                const lvq_bf16 *m, const lvq_bf16 *m_lo, const float *m0, const lvq_bf16 *r, const lvq_bf16 *r_lo, const float *r0,
-                               float c0, int d_ln, float eps, const float *t_tiled, int n, lvq_bf16 *kv, lvq_stream_t stream) {
+                               float c0, int d_ln, float eps, const float *t_tiled, int n, lvq_bf16 *kv, void *ws, size_t ws_bytes,
+                               lvq_stream_t stream) {
     if (batch <= 0 || ny <= 0 || nx <= 0 || cap_tiles <= 0 || d_ln <= 0 || !idx_map || !live_list || !piece_dirty || !counts || !w9 || !m || !m0 || !r ||
         !r0 || !t_tiled || !kv)
         return LVQ_EINVAL;
@@ -892,6 +1278,36 @@ extern "C" int lvq_bev_tile_kv(const float *pillar_feat, const int32_t *idx_map,
     a.te = t_tiled; a.S = batch; a.H = ny; a.W = nx; a.out = kv;
     hipStream_t st = lvq_s(stream);
     const bool x3 = m_lo != nullptr;
+    if (ws != nullptr) {
+        // two launches: conv tokens / rstd / keys of the dirty rows, then a 64-deep projection over contiguous 64-row tiles
+        LvqArena arena(ws, ws_bytes);
+        uint16_t *th = arena.take<uint16_t>((size_t)cap_tiles * 64 * 64);
+        uint16_t *tl = arena.take<uint16_t>((size_t)cap_tiles * 64 * 64);
+        float *rstd = arena.take<float>((size_t)cap_tiles * 64);
+        int32_t *key = arena.take<int32_t>((size_t)cap_tiles * 64);
+        if (!arena.ok) return LVQ_EWORKSPACE;
+        bt::ConvArgs c;
+        c.feat = pillar_feat; c.idx = idx_map; c.live_list = live_list; c.piece_dirty = a.piece_dirty; c.counts = counts; c.w9 = w9; c.b9 = b9;
+        c.rh = r; c.rl = r_lo; c.r0 = r0; c.c0 = c0; c.inv_d = a.inv_d; c.eps = eps; c.S = batch; c.H = ny; c.W = nx;
+        c.th = th; c.tl = x3 ? tl : nullptr; c.rstd = rstd; c.key = key;
+        const size_t lds = (size_t)2 * 2 * bt::TCELLS * 64 * 2 + (size_t)bt::NSLOT * 64 * 4 + 2 * 256 * 4 + (size_t)2 * 4 * bt::TCELLS * 4 + 9 * 64 * 4 +
+                           64 * 4 + 64 * 4 + (size_t)2 * 64 * 64 * 2;
+        static LvqLdsOnce once;
+        if (!lvq_ensure_lds(once, {(const void *)bt::k_conv_rows<false>, (const void *)bt::k_conv_rows<true>}, lds)) return LVQ_ELAUNCH;
+        int64_t grid = (int64_t)lvq_cu_count();
+        if (grid > cap_tiles) grid = cap_tiles;
+        if (x3) hipLaunchKernelGGL((bt::k_conv_rows<true>), dim3((unsigned)grid), dim3(512), lds, st, c);
+        else    hipLaunchKernelGGL((bt::k_conv_rows<false>), dim3((unsigned)grid), dim3(512), lds, st, c);
+        bt::KvRowArgs k;
+        k.th = th; k.tl = x3 ? tl : nullptr; k.rstd = rstd; k.key = key; k.n_rows = counts + 2; k.mh = m; k.ml = m_lo; k.m0 = m0; k.te = t_tiled; k.out = kv;
+        switch (n / 128) {
+            case 2: return launch_kv_rows<2>(k, x3, cap_tiles, st);
+            case 4: return launch_kv_rows<4>(k, x3, cap_tiles, st);
+            case 6: return launch_kv_rows<6>(k, x3, cap_tiles, st);
+            case 8: return launch_kv_rows<8>(k, x3, cap_tiles, st);
+            default: return LVQ_EUNSUPPORTED;
+        }
+    }
     switch (n / 128) {
         case 2: return launch_tile_kv<2>(a, x3, cap_tiles, st);
         case 4: return launch_tile_kv<4>(a, x3, cap_tiles, st);

@@ -386,7 +386,8 @@ class VATLiDAR(_HipModule):
         r_bf, r0, c0, layers = self._kv_fold(C, H, W, feat.device)
         m_bf, m0, t_tab = layers[li]
         ops.bev_tile_kv(feat, idx, live, dirty, counts, cap_rows, batch, H, W, self.refine[0].weight.detach().reshape(C, 9).contiguous(),
-                        self.refine[0].bias, m_bf, m0, r_bf, r0, c0, self.d_model, self.norm_tokens.eps, t_tab, out, tag="bev_kv")
+                        self.refine[0].bias, m_bf, m0, r_bf, r0, c0, self.d_model, self.norm_tokens.eps, t_tab, out, tag="bev_kv",
+                        split_launch=not os.environ.get("LVQ_KV_ONE_LAUNCH"))
 
     def _kv_buffers(self, C: int, H: int, W: int, dev, batch: int) -> List[torch.Tensor]:
         """Per layer ONE K|V buffer [HW + batch*HW, 2d] bf16.  Rows 0 .. HW-1: the per-model TABLE = K|V of the EMPTY scene by the same

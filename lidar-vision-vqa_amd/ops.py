@@ -268,18 +268,28 @@ def bev_tile_tokens(feat: torch.Tensor, idx: torch.Tensor, live: torch.Tensor, d
 
 def bev_tile_kv(feat: torch.Tensor, idx: torch.Tensor, live: torch.Tensor, dirty: torch.Tensor, counts: torch.Tensor, cap_rows: int, batch: int, ny: int,
                 nx: int, w9: torch.Tensor, b9: Optional[torch.Tensor], m: BF, m0: torch.Tensor, r: BF, r0: torch.Tensor, c0: float, d_ln: int, eps: float,
-                t_tiled: torch.Tensor, out: torch.Tensor, tag: Optional[str] = None) -> torch.Tensor:
+                t_tiled: torch.Tensor, out: torch.Tensor, tag: Optional[str] = None, split_launch: bool = True) -> torch.Tensor:
     """K|V rows of the dirty cells straight from the pillar features (lvq_bev_tile_kv: LayerNorm and the K|V projection folded onto the
     64-channel conv token) -> `out` [>= cap_rows, 2n] plain bf16, rows 0 .. counts[2]-1 written."""
     F.require_cuda(feat, idx, live, dirty, counts, w9, b9, m0, r0, t_tiled, out)
     n2 = m[0].shape[0]
     if out.dtype != torch.bfloat16 or not out.is_contiguous() or out.shape[0] < cap_rows or out.shape[1] != n2 or t_tiled.shape[1] != n2:
         raise F.LvqError("bev_tile_kv: `out` must be a contiguous bf16 [>= cap_rows, 2n] buffer and the table [HW, 2n]")
+    L = F.lib()
+    cap_tiles = batch * (ny // 8) * (nx // 8)
+    ws = None
+    if split_launch:
+        nbytes = int(L.lvq_bev_tile_kv_workspace_bytes(F.i64(cap_tiles)))
+        key = (feat.device.index, "tile_kv", torch.cuda.current_stream(feat.device).cuda_stream)
+        ws = _TILE_WS.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=feat.device)
+            _TILE_WS[key] = ws
     with region(tag, feat.device):
-        rc = F.lib().lvq_bev_tile_kv(F.ptr(feat), F.ptr(idx), F.ptr(live), F.ptr(dirty), F.ptr(counts), F.i64(batch * (ny // 8) * (nx // 8)), F.cint(batch),
-                                     F.cint(ny), F.cint(nx), F.cint(feat.shape[1]), F.ptr(w9), F.ptr(b9), F.ptr(m[0]), F.ptr(m[1]), F.ptr(m0), F.ptr(r[0]),
-                                     F.ptr(r[1]), F.ptr(r0), F.cfloat(c0), F.cint(d_ln), F.cfloat(eps), F.ptr(t_tiled), F.cint(n2 // 2), F.ptr(out),
-                                     F.stream_ptr(feat.device))
+        rc = L.lvq_bev_tile_kv(F.ptr(feat), F.ptr(idx), F.ptr(live), F.ptr(dirty), F.ptr(counts), F.i64(cap_tiles), F.cint(batch),
+                               F.cint(ny), F.cint(nx), F.cint(feat.shape[1]), F.ptr(w9), F.ptr(b9), F.ptr(m[0]), F.ptr(m[1]), F.ptr(m0), F.ptr(r[0]),
+                               F.ptr(r[1]), F.ptr(r0), F.cfloat(c0), F.cint(d_ln), F.cfloat(eps), F.ptr(t_tiled), F.cint(n2 // 2), F.ptr(out),
+                               F.ptr(ws), F.csize(ws.numel() if ws is not None else 0), F.stream_ptr(feat.device))
     F.check(rc, "lvq_bev_tile_kv")
     return out
 

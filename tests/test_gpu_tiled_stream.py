@@ -353,6 +353,14 @@ def test_fused_kv_kernel_matches_token_kernel_plus_gemm(prec, monkeypatch):
     vl = pipe.vat_lidar
     kv_f = [b.clone() for b in vl._pe_cache[("kv_buffer", h, w, torch.device(DEV))][1]]
     nd = int(vl._last_tile_counts[2])
+    # the single-kernel form (k_tile_kv) and the default two-launch form (k_conv_rows + k_kv_rows) do the same arithmetic
+    monkeypatch.setenv("LVQ_KV_ONE_LAUNCH", "1")
+    vl._pe_cache.pop(("kv_buffer", h, w, torch.device(DEV)))
+    a1 = pipe(pts, off, patches)
+    for f, o1 in zip(kv_f, vl._pe_cache[("kv_buffer", h, w, torch.device(DEV))][1]):
+        assert torch.equal(f[:h * w + nd], o1[:h * w + nd])
+    assert torch.equal(a["lidar_tokens"], a1["lidar_tokens"])
+    monkeypatch.delenv("LVQ_KV_ONE_LAUNCH")
     monkeypatch.setenv("LVQ_NO_FUSED_KV", "1")
     b = pipe(pts, off, patches)
     kv_u = vl._pe_cache[("kv_buffer", h, w, torch.device(DEV))][1]
