@@ -1046,6 +1046,12 @@ __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
     uint16_t *t_hi = reinterpret_cast<uint16_t *>(smem);                      // [2][64][64] bf16, chunk-swizzled, filled by LDS-DMA
     uint16_t *t_lo = t_hi + 2 * TCELLS * C;
     float *pbias = reinterpret_cast<float *>(t_lo + 2 * TCELLS * C);          // [N] m0 of this half
+    // output staging: the MFMA layout gives a lane 4 columns of one row per column tile -- stored directly that is 8 bytes per lane,
+    // 32 contiguous bytes per row and request, and the store path was 2.1 of the kernel's 4.4 ms.  The 16 x N block of a 16-row
+    // group goes through LDS instead (rows padded by 16 B: the 16 rows of a request would otherwise share their banks) and leaves as
+    // 1-KiB wave stores along the rows.  Two buffers: group q + 1 is written while group q is being read out.
+    constexpr int SROW = N + 8;
+    uint16_t *sbuf = reinterpret_cast<uint16_t *>(pbias + N);                 // [2][16][SROW] bf16
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l15 = lane & 15, g4 = lane >> 4;
     const int64_t n_rows = *a.n_rows;
     const int64_t n_groups = (n_rows + TCELLS - 1) / TCELLS;
@@ -1154,7 +1160,8 @@ __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
         auto emit = [&](int gq, const f32x4 (&te)[2 * JH], const float rs, const bool valid) {
             bf16x8 th0, th1, tl0, tl1;
             load_t(buf, gq, th0, th1, tl0, tl1);
-            uint16_t *dst = a.out + (g * TCELLS + gq * 16 + l15) * (2 * N) + ncol0 + col0;
+            uint16_t *sb = sbuf + (gq & 1) * 16 * SROW;
+            uint16_t *dst = sb + l15 * SROW + col0;
             auto half_out = [&](auto hf_tag) {
                 constexpr int HF = decltype(hf_tag)::value;
                 f32x4 acc[JH];
@@ -1166,14 +1173,22 @@ __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
                     oh[2 * jj] = pack_bf16(acc[jj][0] * rs + tv[0], acc[jj][1] * rs + tv[1]);
                     oh[2 * jj + 1] = pack_bf16(acc[jj][2] * rs + tv[2], acc[jj][3] * rs + tv[3]);
                 }
-                if (valid) {
 #pragma unroll
-                    for (int jj = 0; jj < JH; ++jj)
-                        *reinterpret_cast<uint2 *>(dst + 16 * (HF * JH + jj)) = make_uint2(oh[2 * jj], oh[2 * jj + 1]);
-                }
+                for (int jj = 0; jj < JH; ++jj)
+                    *reinterpret_cast<uint2 *>(dst + 16 * (HF * JH + jj)) = make_uint2(oh[2 * jj], oh[2 * jj + 1]);
             };
             half_out(std::integral_constant<int, 0>{});
             half_out(std::integral_constant<int, 1>{});
+            __syncthreads();                                      // the 16 x N block is complete
+            constexpr int UPR = N / 8;                            // 16-byte units per row
+#pragma unroll
+            for (int i = 0; i < N / 256; ++i) {
+                const int u = (wid * (N / 256) + i) * 64 + lane, row = u / UPR, c16 = u - row * UPR;
+                const int64_t r = g * TCELLS + gq * 16 + row;
+                if (r < n_rows)
+                    *reinterpret_cast<u32x4 *>(a.out + r * (2 * N) + ncol0 + c16 * 8) = *reinterpret_cast<const u32x4 *>(sb + row * SROW + c16 * 8);
+            }
+            (void)valid;
         };
         f32x4 te_a[2 * JH], te_b[2 * JH];
         float rs_a, rs_b;
@@ -1237,7 +1252,7 @@ template <int J> static int launch_tile_kv(const bt::KvArgs &a, bool x3, int64_t
 // K|V rows of the dirty cells straight from the pillar features (k_tile_kv): refine conv + GELU -> t, then
 // kv = rstd (M t + m0) + T[key] with rstd = 1 / sqrt((|R t + r0|^2 + c0) / d_ln + eps).  n = d (the K and the V half are n columns each).
 template <int J> static int launch_kv_rows(const bt::KvRowArgs &a, bool x3, int64_t cap_tiles, hipStream_t st) {
-    const size_t lds = (size_t)2 * 2 * bt::TCELLS * 64 * 2 + (size_t)128 * J * 4;
+    const size_t lds = (size_t)2 * 2 * bt::TCELLS * 64 * 2 + (size_t)128 * J * 4 + (size_t)2 * 16 * (128 * J + 8) * 2;
     static LvqLdsOnce once;
     if (lds > 64 * 1024 && !lvq_ensure_lds(once, {(const void *)bt::k_kv_rows<J, false>, (const void *)bt::k_kv_rows<J, true>}, lds)) return LVQ_ELAUNCH;
     int64_t grid = (int64_t)lvq_cu_count();
