@@ -298,10 +298,11 @@ def main():
     roofline_bev_kv = None
     bk_ms = avg_ms(events.get("bev_kv", []))
     if bk_ms:
-        nbytes = live_rows * (2 * 2 * d) + (h * w) * (2 * d) * 4 + S * h * w * 4      # K|V rows out (bf16) + the table T once (fp32) + index map
+        # K|V rows out (bf16) + the table T once (fp32) + index map + the (t hi, t lo, rstd, key) rows written and read between the two launches
+        nbytes = live_rows * (2 * 2 * d) + (h * w) * (2 * d) * 4 + S * h * w * 4 + 2 * live_rows * (256 + 8)
         ex_flops = 2.0 * live_rows * (2 * d + 64) * 64 * {"bf16": 1, "mixed": 3, "bf16x3": 3}[prec]
         tr, src = profile_traffic([f"k_tile_kv S={S} {prec}"])
-        roofline_bev_kv = {"bound": "hbm", "kernel": "k_tile_kv (pillar halo gather + depthwise 3x3 + GELU -> 64-channel token t -> K|V = rstd (M t + m0) + T[key] "
+        roofline_bev_kv = {"bound": "hbm", "kernel": "lvq_bev_tile_kv = k_conv_rows + k_kv_rows (pillar halo gather + depthwise 3x3 + GELU -> 64-channel token t -> K|V = rstd (M t + m0) + T[key] "
                            f"for the {live_rows} dirty cells of {S * h * w}; LayerNorm and the 768-deep K|V projection folded into a 64-deep one)",
                            "achieved": round(nbytes / (bk_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                            "frac": round(nbytes / (bk_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": nbytes, "traffic": tr, "traffic_source": src,
