@@ -1254,8 +1254,12 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
     // 256x256 / two 64-KiB slots: 2/3 of the L2->LDS fill bytes of the 256x128 tile (the bound on these projections);
     // whole tiles only, and enough of them that the coarser grid still fills the 256 CUs several times over
     static LvqLdsOnce once256;      // per device: did the runtime grant 160 KiB of dynamic LDS?
+    // ... or, below that, when one tile per CU keeps >= 80 % of the CUs of its last dispatch round busy (18432 x 768: 216 tiles in one
+    // round, 0.150 -> ~0.1 ms per x3 GEMM of the query side; 260 tiles would be two rounds for four tiles and stay on the smaller kernels)
     static const int64_t min256 = getenv("LVQ_GEMM_256X256_MIN_TILES") ? atoll(getenv("LVQ_GEMM_256X256_MIN_TILES")) : 1024;
-    if (dma && g.vec_epilogue && m % 256 == 0 && n % 256 == 0 && (m / 256) * (n / 256) * batch >= min256 &&
+    const int64_t t256 = (m / 256) * (n / 256) * batch, cus = lvq_cu_count();
+    const bool round_ok = t256 >= 200 && t256 * 5 >= ((t256 + cus - 1) / cus) * cus * 4;
+    if (dma && g.vec_epilogue && m % 256 == 0 && n % 256 == 0 && (t256 >= min256 || (round_ok && getenv("LVQ_GEMM_256X256_MIN_TILES") == nullptr)) &&
         (m / 256) * (n / 256) <= 0x7fffffff && getenv("LVQ_GEMM_NO256X256") == nullptr && getenv("LVQ_GEMM_NO256") == nullptr) {
         const size_t lds = (size_t)5 * 256 * 128;              // A ring 3 x 32 KiB + W ring 2 x 32 KiB
         if (lvq_ensure_lds(once256, {(const void *)k_gemm_256<0, 0>, (const void *)k_gemm_256<1, 0>, (const void *)k_gemm_256<0, 1>,
