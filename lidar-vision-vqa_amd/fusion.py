@@ -360,12 +360,12 @@ class VATLiDAR(_HipModule):
             return hit[1]
         split = self._split()
         d = self.d_model
-        f64 = lambda p: p.detach().to(device=dev, dtype=torch.float64)
+        f64 = lambda p: p.detach().to(device="cpu", dtype=torch.float64)      # the small factors: host fp64 (a 768 x 65 QR, two thin products)
         wp, bp = f64(self.proj.weight).view(d, C), f64(self.proj.bias)
         wc, bc = wp - wp.mean(0, keepdim=True), bp - bp.mean()
         rr = torch.linalg.qr(torch.cat((wc, bc[:, None]), 1), mode="r").R          # [C + 1, C + 1]: |Wc t + bc|^2 = |R [t; 1]|^2
-        r_bf = ops.cast(rr[:C, :C].float().contiguous(), split)
-        r0 = rr[:C, C].float().contiguous()
+        r_bf = ops.cast(rr[:C, :C].float().contiguous().to(dev), split)
+        r0 = rr[:C, C].float().contiguous().to(dev)
         c0 = float(rr[C, C] ** 2)
         gam, bet = f64(self.norm_tokens.weight), self.norm_tokens.bias.detach().float().view(1, d).contiguous()
         a_pe = ops.cast(ops.scale_add_rows(self._pe_tiled(H, W, dev), bet), split)  # beta + PE[key], the A operand of the table GEMM
@@ -373,8 +373,8 @@ class VATLiDAR(_HipModule):
         for blk in self.blocks:
             blk.precision = self.precision
             wkv = f64(blk.ca.in_proj_weight)[d:]
-            m_bf = ops.cast((wkv @ (gam[:, None] * wc)).float().contiguous(), split)
-            m0 = (wkv @ (gam * bc)).float().contiguous()
+            m_bf = ops.cast((wkv @ (gam[:, None] * wc)).float().contiguous().to(dev), split)
+            m0 = (wkv @ (gam * bc)).float().contiguous().to(dev)
             t_tab, _ = ops.linear(a_pe, blk._w(blk.ca.in_proj_weight), blk.ca.in_proj_bias, out_f32=True, w_rows=(d, 3 * d))
             layers.append((m_bf, m0, t_tab))
         fold = (r_bf, r0, c0, layers)
