@@ -37,7 +37,7 @@ import torch
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (never the 2:1-sparse figure)
 PEAK_HBM_GBS = 8000.0
 TOL = 1e-3                  # north_star: fused tokens within 1e-3 of the fp32 CPU path
-MODES = ("mixed", "bf16", "bf16x3")
+MODES = ("mixed", "mixed16", "bf16", "bf16x3")
 
 
 def avg_ms(pairs):
@@ -259,8 +259,9 @@ def main():
     if kv_ms:
         ach = kv_flops / (kv_ms * 1e-3) / 1e12
         form = {"bf16": "plain operands: 1 MFMA pass", "mixed": "A plain, W hi+lo: 2 MFMA passes (executed FLOPs = 2x algorithmic)",
+                "mixed16": "A plain, W hi+lo: 2 MFMA passes (executed FLOPs = 2x algorithmic)",
                 "bf16x3": "A and W hi+lo: 3 MFMA passes (executed FLOPs = 3x algorithmic)"}[prec]
-        ex = {"bf16": 1, "mixed": 2, "bf16x3": 3}[prec]
+        ex = {"bf16": 1, "mixed": 2, "mixed16": 2, "bf16x3": 3}[prec]
         tr, src = profile_traffic([f"k_gemm_256 M={kv_rows} N={2 * d} K={d} {prec}"])
         roofline_kv = {"bound": "mfma", "kernel": "k_gemm_256 (256x256 tile, LDS-DMA, A ring 3 / W ring 2; VATLiDAR.ca K|V projection over the dirty BEV cells, "
                        f"M = {kv_rows} of {S * h * w} BEV cells, N=2d, K=d); " + form,
@@ -274,8 +275,9 @@ def main():
     if at_ms:
         ach = at_flops / (at_ms * 1e-3) / 1e12
         form = {"bf16": "Q, K, P, V plain: 1 MFMA pass", "mixed": "Q hi+lo (2 MFMA passes over QK^T), K, P, V plain: executed FLOPs = 1.5x algorithmic",
+                "mixed16": "Q one fp16 operand against fp16 K (1 MFMA pass over QK^T), P, V plain bf16",
                 "bf16x3": "all operands hi+lo: executed FLOPs = 3x algorithmic"}[prec]
-        ex = {"bf16": 1.0, "mixed": 1.5, "bf16x3": 3.0}[prec]
+        ex = {"bf16": 1.0, "mixed": 1.5, "mixed16": 1.0, "bf16x3": 3.0}[prec]
         # keys the launch actually streams: block 0's queries are scene-independent, so a scene streams only its dirty cells, twice
         # (computed rows added, the table rows of the same cells subtracted from the per-model totals) -- read back after the timed region
         pi = getattr(pipe.vat_lidar.blocks[0], "_last_pair_info", None)
@@ -300,7 +302,7 @@ def main():
     if bk_ms:
         # K|V rows out (bf16) + the table T once (fp32) + index map + the (t hi, t lo, rstd, key) rows written and read between the two launches
         nbytes = live_rows * (2 * 2 * d) + (h * w) * (2 * d) * 4 + S * h * w * 4 + 2 * live_rows * (256 + 8)
-        ex_flops = 2.0 * live_rows * (2 * d + 64) * 64 * {"bf16": 1, "mixed": 3, "bf16x3": 3}[prec]
+        ex_flops = 2.0 * live_rows * (2 * d + 64) * 64 * {"bf16": 1, "mixed": 3, "mixed16": 3, "bf16x3": 3}[prec]
         tr, src = profile_traffic([f"k_tile_kv S={S} {prec}"])
         roofline_bev_kv = {"bound": "hbm", "kernel": "lvq_bev_tile_kv = k_conv_rows + k_kv_rows (pillar halo gather + depthwise 3x3 + GELU -> 64-channel token t -> K|V = rstd (M t + m0) + T[key] "
                            f"for the {live_rows} dirty cells of {S * h * w}; LayerNorm and the 768-deep K|V projection folded into a 64-deep one)",

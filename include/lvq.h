@@ -252,12 +252,13 @@ int lvq_bev_tile_tokens(const float *pillar_feat, const int32_t *idx_map, const 
  * vat_lidar.py:222-248 + vat_blocks.py:42 folded once per weights version (exact algebra; the 768-deep projection becomes 64-deep).
  * m_lo / r_lo != NULL: t, M and R as hi + lo (three products).  kv [dirty rows, 2 n] bf16: the compact rows numbered by lvq_bev_tiles.
  * ws != NULL (lvq_bev_tile_kv_workspace_bytes(cap_tiles)): two launches -- k_conv_rows stores (t, rstd, key) of the dirty rows, k_kv_rows
- * projects contiguous 64-row tiles -- instead of the single kernel; the same arithmetic, bit-identical rows. */
+ * projects contiguous 64-row tiles -- instead of the single kernel; the same arithmetic, bit-identical rows.  k_fp16 != 0 (two-launch
+ * form only): the K half (columns 0 .. n-1) is stored as IEEE fp16 for the fp16 Q K^T pass of the attention entry points. */
 size_t lvq_bev_tile_kv_workspace_bytes(int64_t cap_tiles);
 int lvq_bev_tile_kv(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *piece_dirty,
                     const int32_t *counts, int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9,
                     const lvq_bf16 *m, const lvq_bf16 *m_lo, const float *m0, const lvq_bf16 *r, const lvq_bf16 *r_lo, const float *r0, float c0,
-                    int d_ln, float eps, const float *t_tiled, int n, lvq_bf16 *kv, void *ws, size_t ws_bytes, lvq_stream_t stream);
+                    int d_ln, float eps, const float *t_tiled, int n, int k_fp16, lvq_bf16 *kv, void *ws, size_t ws_bytes, lvq_stream_t stream);
 /* c[0 .. *m_rows_dev) = a @ w^T + bias over the live rows only (the row count stays on the device); m_cap, n multiples of 256,
  * k of 64.  Operand forms as lvq_gemm_bf16 (plain | a plain, w hi + lo | both hi + lo). */
 int lvq_gemm_bf16_live_rows(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,
@@ -266,11 +267,13 @@ int lvq_gemm_bf16_live_rows(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_b
 /* softmax(q K^T * scale) V over the tiled stream: key slot r (0..63) of tile t of batch b is row row_src[(b * n_tiles + t) * 64 + r] of
  * k_rows / v_rows -- ONE K|V buffer holding the per-model table rows and the computed rows of every batch (lvq_bev_tiles' row_src).
  * Shapes of lvq_attention_stream_ok(nq, 64 * n_tiles, 64) only; q plain or hi + lo (mixed mode), K / V plain.
+ * k_fp16 != 0 ("mixed16"): the K columns of the buffer hold IEEE fp16 (lvq_bev_tile_kv with k_fp16), q (hi + lo summed) is rounded once
+ * to fp16 and Q K^T runs as ONE fp16 MFMA pass; P and V stay bf16.  The caller guarantees |K|, |q * scale * log2 e| < 65504.
  * Workspace: lvq_attention_workspace_bytes(batch, n_heads, nq, 64 * n_tiles, 64, 1). */
 int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_rows, const lvq_bf16 *v_rows, const int32_t *row_src,
                              int batch, int n_heads, int nq, int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride,
-                             int64_t ldkv, int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o,
-                             lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream);
+                             int64_t ldkv, int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, int k_fp16,
+                             lvq_bf16 *o, lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream);
 
 /* Attention over the DIRTY rows only, for queries that do not depend on the batch (VATLiDAR's first block, vat_lidar.py:259-270 (q = self.query expanded over the batch + view embedding) and 283-288 (blocks) +
  * vat_blocks.py:37-42: learned queries -> self-attention -> ca_ln -> W_q).  With the fixed softmax reference the contribution of a
@@ -286,7 +289,7 @@ int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_
  *       predicated second launch.  Not bit-identical to the full stream (fp32 accumulation order); same operand roundings. */
 size_t lvq_attention_stream_totals_workspace_bytes(int n_heads, int nq, int nkv, int dh);
 int lvq_attention_bf16_stream_totals(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k, const lvq_bf16 *v, int n_heads, int nq,
-                                     int nkv, int dh, int64_t ldq, int64_t q_hstride, int64_t ldkv, int64_t kv_hstride, float scale,
+                                     int nkv, int dh, int64_t ldq, int64_t q_hstride, int64_t ldkv, int64_t kv_hstride, float scale, int k_fp16,
                                      float *totals, void *ws, size_t ws_bytes, lvq_stream_t stream);
 int lvq_bev_scene_pairs(const int32_t *row_src, int batch, int n_tiles, int row_base, int cap_tiles, int32_t *pair_src, int32_t *pair_info,
                         lvq_stream_t stream);
@@ -294,7 +297,7 @@ size_t lvq_attention_tiled_signed_workspace_bytes(int batch, int n_heads, int nq
 int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_rows, const lvq_bf16 *v_rows,
                                     const int32_t *row_src, const int32_t *pair_src, const int32_t *pair_info, int pair_cap_tiles, const float *totals, int batch, int n_heads, int nq,
                                     int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv,
-                                    int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o,
+                                    int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, int k_fp16, lvq_bf16 *o,
                                     lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream);
 
 /* 1 when the long-stream kernel takes (nq, nkv, dh) without bias / mask: head_dim 64, nkv >= 4096 and a multiple of 64, query

@@ -54,6 +54,13 @@ struct AttnArgs {
 constexpr int KVB = 64;  // keys per tile
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+// two fp32 -> packed fp16 pair, round to nearest even (v_cvt_f16_f32 x 2; NOT v_cvt_pkrtz, which truncates)
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+    f16x2_t p = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, p);
+}
 
 // two fp32 -> packed bf16 pair (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserved)
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -538,6 +545,9 @@ __device__ __forceinline__ void lds_tr_wait4(bf16x4 &a, bf16x4 &b, bf16x4 &c, bf
 // the same accumulator -- while K, V and P stay plain bf16.  Rounding Q is the same perturbation for every key of a row, so it
 // does not average out over the stream the way the per-key roundings of K, V and P do (tools/precision_study.py: 2.8e-3 of the
 // 1e-3 budget at 262 144 keys); splitting it costs 4 of 12 MFMAs per 32-key block and 16 VGPRs, nothing in LDS or HBM.
+// QS = 2 ("mixed16"): Q as ONE fp16 operand (hi + lo summed, scaled, rounded to 11 bits) against K stored as fp16 -- one MFMA per K
+// fragment at the bf16 rate; P and V stay bf16.  Q's rounding is common to all keys of a row, so the result carries ~3.5x the error of
+// QS = 1 (3.7e-4 instead of 1.1e-4 on the bench scene), for 2/3 of its MFMA passes.
 template <int NW, int QS, int TL = 0>
 __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     constexpr int DH = 64, KROW = 64, CH = 8, NT = NW * 64;
@@ -563,19 +573,23 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     const float cexp0 = a.scale * 1.4426950408889634f;
 
     // Q^T fragments, pre-multiplied by scale * log2(e): lane supplies Q[qi][16 ks + 8 hi .. +7]
-    bf16x8 qf[4], qfl[QS ? 4 : 1];
+    bf16x8 qf[4], qfl[QS == 1 ? 4 : 1];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         uint4 v = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
         const int64_t qo = (int64_t)b * a.q_bs + (int64_t)qi * a.ldq + (int64_t)h * a.q_hs + 16 * ks + 8 * hi;
         if (qi < a.Nq) {
             v = *reinterpret_cast<const uint4 *>(a.q + qo);
-            if (QS) vl = *reinterpret_cast<const uint4 *>(a.ql + qo);
+            if (QS && a.ql) vl = *reinterpret_cast<const uint4 *>(a.ql + qo);
         }
         uint32_t *w = reinterpret_cast<uint32_t *>(&v), *wl = reinterpret_cast<uint32_t *>(&vl);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (QS) {           // (hi + lo) * c in fp32, split again: hi' = bf16(x), lo' = bf16(x - hi')
+            if (QS == 2) {      // (hi + lo) * c in fp32 -> fp16 (round to nearest even)
+                const float x0 = (__uint_as_float(w[e] << 16) + __uint_as_float(wl[e] << 16)) * cexp0;
+                const float x1 = (__uint_as_float(w[e] & 0xffff0000u) + __uint_as_float(wl[e] & 0xffff0000u)) * cexp0;
+                w[e] = pack_f16(x0, x1);
+            } else if (QS) {    // (hi + lo) * c in fp32, split again: hi' = bf16(x), lo' = bf16(x - hi')
                 const float x0 = (__uint_as_float(w[e] << 16) + __uint_as_float(wl[e] << 16)) * cexp0;
                 const float x1 = (__uint_as_float(w[e] & 0xffff0000u) + __uint_as_float(wl[e] & 0xffff0000u)) * cexp0;
                 const uint32_t hb = pack_bf16(x0, x1);
@@ -586,7 +600,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
             }
         }
         qf[ks] = *reinterpret_cast<bf16x8 *>(&v);
-        if (QS) qfl[ks] = *reinterpret_cast<bf16x8 *>(&vl);
+        if (QS == 1) qfl[ks] = *reinterpret_cast<bf16x8 *>(&vl);
     }
     f32x16 o[2];
 #pragma unroll
@@ -711,8 +725,9 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + (kb * 32 + l31) * KROW + (((2 * ks + hi) ^ fk) << 3));
-                sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
-                if (QS) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[ks], sc[kb], 0, 0, 0);
+                if (QS == 2) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qf[ks]), sc[kb], 0, 0, 0);
+                else         sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
+                if (QS == 1) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[ks], sc[kb], 0, 0, 0);
             }
         }
     };
@@ -778,8 +793,9 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + (kb * 32 + l31) * KROW + (((2 * ks + hi) ^ fk) << 3));
-                sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
-                if (QS) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[ks], sc, 0, 0, 0);
+                if (QS == 2) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qf[ks]), sc, 0, 0, 0);
+                else         sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
+                if (QS == 1) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[ks], sc, 0, 0, 0);
             }
             // rows rb + {0, 8} (step 0) and rb + {16, 24} (step 1) of this 32-key block: byte immediates (32 kb + 8 j) * 128
             bf16x4 a00, a01, a10, a11, b00, b01, b10, b11;
@@ -1269,8 +1285,11 @@ extern "C" size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, 
 extern "C" int lvq_attention_stream_ok(int nq, int nkv, int dh) { return plan_k32_waves(nq, nkv, dh, false) != 0; }
 
 namespace {
-template <int TL> void launch_k32(const AttnArgs &a, int nw, bool qs, int64_t nwg, size_t lds, hipStream_t st) {
-    if (qs) {
+template <int TL> void launch_k32(const AttnArgs &a, int nw, int qs, int64_t nwg, size_t lds, hipStream_t st) {
+    if (qs == 2) {
+        if (nw == 6) hipLaunchKernelGGL((k_attn32<6, 2, TL>), dim3((unsigned)nwg), dim3(384), lds, st, a);
+        else         hipLaunchKernelGGL((k_attn32<4, 2, TL>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    } else if (qs) {
         if (nw == 6) hipLaunchKernelGGL((k_attn32<6, 1, TL>), dim3((unsigned)nwg), dim3(384), lds, st, a);
         else         hipLaunchKernelGGL((k_attn32<4, 1, TL>), dim3((unsigned)nwg), dim3(256), lds, st, a);
     } else {
@@ -1288,7 +1307,7 @@ constexpr size_t K32_LDS_TILED = K32_LDS + 2 * 8 * KVB * sizeof(int32_t);       
 extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k_rows, const lvq_bf16 *v_rows,
                                         const int32_t *row_src, int batch, int n_heads, int nq, int n_tiles, int dh, int64_t q_bstride, int64_t ldq,
                                         int64_t q_hstride, int64_t ldkv, int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride,
-                                        float scale, lvq_bf16 *o, lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+                                        float scale, int k_fp16, lvq_bf16 *o, lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream) {
     if (batch <= 0 || n_heads <= 0 || nq < 0 || n_tiles <= 0 || !q || !k_rows || !v_rows || !row_src || !o) return LVQ_EINVAL;
     if (nq == 0) return LVQ_OK;
     const int64_t nkv64 = (int64_t)n_tiles * KVB;
@@ -1318,7 +1337,7 @@ extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo,
     const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
     const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;
     if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
-    launch_k32<1>(a, pl.k32, q_lo != nullptr, nwg, K32_LDS_TILED, st);
+    launch_k32<1>(a, pl.k32, k_fp16 ? 2 : (q_lo != nullptr ? 1 : 0), nwg, K32_LDS_TILED, st);
     if (a.nsplit > 1) {
         const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
         hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
@@ -1344,7 +1363,7 @@ extern "C" size_t lvq_attention_stream_totals_workspace_bytes(int n_heads, int n
 }
 extern "C" int lvq_attention_bf16_stream_totals(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k, const lvq_bf16 *v, int n_heads, int nq,
                                                 int nkv, int dh, int64_t ldq, int64_t q_hstride, int64_t ldkv, int64_t kv_hstride, float scale,
-                                                float *totals, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+                                                int k_fp16, float *totals, void *ws, size_t ws_bytes, lvq_stream_t stream) {
     if (n_heads <= 0 || nq <= 0 || nkv <= 0 || !q || !k || !v || !totals) return LVQ_EINVAL;
     if (dh != 64 || (ldq & 7) || (ldkv & 7) || (q_hstride & 7) || (kv_hstride & 7) || n_heads > 65535) return LVQ_EUNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)q_lo | (uintptr_t)k | (uintptr_t)v | (uintptr_t)totals) & 15) return LVQ_EUNSUPPORTED;
@@ -1362,7 +1381,7 @@ extern "C" int lvq_attention_bf16_stream_totals(const lvq_bf16 *q, const lvq_bf1
     hipStream_t st = lvq_s(stream);
     const size_t lds = K32_LDS;
     const int64_t ngrp = (int64_t)a.H * a.nsplit;
-    launch_k32<0>(a, pl.k32, q_lo != nullptr, (ngrp + 7) / 8 * 8 * a.nqt, lds, st);
+    launch_k32<0>(a, pl.k32, k_fp16 ? 2 : (q_lo != nullptr ? 1 : 0), (ngrp + 7) / 8 * 8 * a.nqt, lds, st);
     const int64_t total = (int64_t)a.H * a.Nq * (a.dh / 4);
     hipLaunchKernelGGL(k_attn_combine_raw, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a, totals);
     return lvq_launch_status();
@@ -1382,8 +1401,8 @@ extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16
                                                const int32_t *row_src, const int32_t *pair_src,
                                                const int32_t *pair_info, int pair_cap_tiles, const float *totals, int batch, int n_heads, int nq,
                                                int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv,
-                                               int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, lvq_bf16 *o,
-                                               lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+                                               int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, int k_fp16,
+                                               lvq_bf16 *o, lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream) {
     if (batch <= 0 || n_heads <= 0 || nq < 0 || n_tiles <= 0 || pair_cap_tiles <= 0 || !q || !k_rows || !v_rows || !row_src || !pair_src ||
         !pair_info || !totals || !o)
         return LVQ_EINVAL;
@@ -1420,11 +1439,12 @@ extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16
     const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
     if (hipMemsetAsync(flags, 0, (size_t)batch * n_heads * sizeof(int32_t), st) != hipSuccess) return LVQ_ELAUNCH;
     a.flags = flags;
-    launch_k32<2>(a, pl.k32, q_lo != nullptr, nwg, lds, st);
+    const int qs = k_fp16 ? 2 : (q_lo != nullptr ? 1 : 0);
+    launch_k32<2>(a, pl.k32, qs, nwg, lds, st);
     hipLaunchKernelGGL(k_attn_combine_signed, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
     // predicated full re-run of the flagged (batch, head) pairs: every workgroup of an unflagged pair returns at once
     a.flags = nullptr; a.pred = flags; a.pair_src = nullptr; a.pair_info = nullptr; a.totals = nullptr;
-    launch_k32<1>(a, pl.k32, q_lo != nullptr, nwg, lds, st);
+    launch_k32<1>(a, pl.k32, qs, nwg, lds, st);
     hipLaunchKernelGGL(k_attn_combine_signed, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
     return lvq_launch_status();
 }

@@ -29,6 +29,11 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     bf16x2_t p = {(__bf16)a, (__bf16)b};
     return *reinterpret_cast<uint32_t *>(&p);
 }
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {          // round to nearest even (not v_cvt_pkrtz)
+    f16x2_t p = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(uint32_t, p);
+}
 
 constexpr int TS = 8, TCELLS = 64;                 // tile side (cells), keys per tile
 constexpr int NPIECE = 8, PCELLS = 8;              // pieces per tile, cells per piece (2 rows x 4 columns)
@@ -1035,7 +1040,8 @@ struct KvRowArgs {
     const uint16_t *mh, *ml;      // M [2 N, 64] bf16 hi / lo
     const float *m0;              // [2 N]
     const float *te;              // T [keys, 2 N] fp32
-    uint16_t *out;                // K|V rows [n, 2 N] bf16
+    uint16_t *out;                // K|V rows [n, 2 N] bf16 (the K half as IEEE fp16 when k_fp16)
+    int k_fp16;
 };
 
 template <int J, bool X3>
@@ -1066,6 +1072,7 @@ __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
     const int64_t x_begin = (int64_t)xcd * per_x, x_end = x_begin + per_x < n_groups ? x_begin + per_x : n_groups;
     const int64_t g_begin = x_begin + wg_r, g_end = x_end, g_step = wg_R;
     const int ncol0 = half * N;
+    const bool as_f16 = a.k_fp16 != 0 && half == 0;             // workgroup-uniform: the K half leaves as fp16 ("mixed16")
     for (int e = tid; e < N; e += 512) pbias[e] = a.m0[ncol0 + e];
 
     bf16x8 wf[J][2], wfl[X3 ? J : 1][2];
@@ -1170,8 +1177,13 @@ __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
 #pragma unroll
                 for (int jj = 0; jj < JH; ++jj) {
                     const f32x4 tv = te[HF * JH + jj];
-                    oh[2 * jj] = pack_bf16(acc[jj][0] * rs + tv[0], acc[jj][1] * rs + tv[1]);
-                    oh[2 * jj + 1] = pack_bf16(acc[jj][2] * rs + tv[2], acc[jj][3] * rs + tv[3]);
+                    if (as_f16) {
+                        oh[2 * jj] = pack_f16(acc[jj][0] * rs + tv[0], acc[jj][1] * rs + tv[1]);
+                        oh[2 * jj + 1] = pack_f16(acc[jj][2] * rs + tv[2], acc[jj][3] * rs + tv[3]);
+                    } else {
+                        oh[2 * jj] = pack_bf16(acc[jj][0] * rs + tv[0], acc[jj][1] * rs + tv[1]);
+                        oh[2 * jj + 1] = pack_bf16(acc[jj][2] * rs + tv[2], acc[jj][3] * rs + tv[3]);
+                    }
                 }
 #pragma unroll
                 for (int jj = 0; jj < JH; ++jj)
@@ -1277,12 +1289,13 @@ extern "C" size_t lvq_bev_tile_kv_workspace_bytes(int64_t cap_tiles) {
 extern "C" int lvq_bev_tile_kv(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *piece_dirty,
                                const int32_t *counts, int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9,
                                const lvq_bf16 *m, const lvq_bf16 *m_lo, const float *m0, const lvq_bf16 *r, const lvq_bf16 *r_lo, const float *r0,
-                               float c0, int d_ln, float eps, const float *t_tiled, int n, lvq_bf16 *kv, void *ws, size_t ws_bytes,
+                               float c0, int d_ln, float eps, const float *t_tiled, int n, int k_fp16, lvq_bf16 *kv, void *ws, size_t ws_bytes,
                                lvq_stream_t stream) {
     if (batch <= 0 || ny <= 0 || nx <= 0 || cap_tiles <= 0 || d_ln <= 0 || !idx_map || !live_list || !piece_dirty || !counts || !w9 || !m || !m0 || !r ||
         !r0 || !t_tiled || !kv)
         return LVQ_EINVAL;
     if ((m_lo == nullptr) != (r_lo == nullptr)) return LVQ_EINVAL;
+    if (k_fp16 && ws == nullptr) return LVQ_EUNSUPPORTED;          // the fp16 K half is a feature of the two-launch form
     if (c_in != 64 || (ny % 8) || (nx % 8) || (n % 256) || n < 256 || n > 1024) return LVQ_EUNSUPPORTED;
     if (((uintptr_t)pillar_feat | (uintptr_t)m | (uintptr_t)m_lo | (uintptr_t)r | (uintptr_t)r_lo | (uintptr_t)m0 | (uintptr_t)r0 | (uintptr_t)t_tiled |
          (uintptr_t)kv) & 15)
@@ -1314,7 +1327,7 @@ extern "C" int lvq_bev_tile_kv(const float *pillar_feat, const int32_t *idx_map,
         if (x3) hipLaunchKernelGGL((bt::k_conv_rows<true>), dim3((unsigned)grid), dim3(512), lds, st, c);
         else    hipLaunchKernelGGL((bt::k_conv_rows<false>), dim3((unsigned)grid), dim3(512), lds, st, c);
         bt::KvRowArgs k;
-        k.th = th; k.tl = x3 ? tl : nullptr; k.rstd = rstd; k.key = key; k.n_rows = counts + 2; k.mh = m; k.ml = m_lo; k.m0 = m0; k.te = t_tiled; k.out = kv;
+        k.th = th; k.tl = x3 ? tl : nullptr; k.rstd = rstd; k.key = key; k.n_rows = counts + 2; k.mh = m; k.ml = m_lo; k.m0 = m0; k.te = t_tiled; k.out = kv; k.k_fp16 = k_fp16;
         switch (n / 128) {
             case 2: return launch_kv_rows<2>(k, x3, cap_tiles, st);
             case 4: return launch_kv_rows<4>(k, x3, cap_tiles, st);

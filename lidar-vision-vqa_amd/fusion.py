@@ -48,12 +48,12 @@ class _HipModule(nn.Module):
 
     def _split(self) -> bool:
         """Operands travel as hi + lo (bf16x3, and mixed outside its plain key stream)."""
-        return self._mode() in ("bf16x3", "mixed")
+        return self._mode() in ("bf16x3", "mixed", "mixed16")
 
     def _stream_plain(self, nq: int, nkv: int, dh: int) -> bool:
         """mixed mode, and the K/V side of this attention is a long key stream whose per-key roundings average out: x, K, V, P
         stay plain bf16 there (ops docstring) while the weights and the query side keep their lo parts."""
-        return self._mode() == "mixed" and ops.attention_stream_ok(nq, nkv, dh)
+        return self._mode() in ("mixed", "mixed16") and ops.attention_stream_ok(nq, nkv, dh)
 
     def _w(self, p: torch.Tensor, pad_k: int = 0) -> BF:
         """bf16 (hi[, lo]) copy of a weight matrix [N,K]; rebuilt when the parameter changes."""
@@ -147,7 +147,7 @@ class VATBlock(_HipModule):
         return q2, qp
 
     def forward_tokens_tiled_signed(self, q2_1: torch.Tensor, qp: BF, totals: torch.Tensor, x_rows: BF, kv: torch.Tensor, row_src: torch.Tensor,
-                                    rows_dev: torch.Tensor, B: int, nq: int, n_tiles: int) -> torch.Tensor:
+                                    rows_dev: torch.Tensor, B: int, nq: int, n_tiles: int, k_fp16: bool = False) -> torch.Tensor:
         """forward_tokens_tiled for scene-independent queries: the attention streams each scene's DIRTY rows only (twice: the computed
         rows added, the table rows of the same cells subtracted from the per-model `totals`), csrc/attention.hip `signed pair stream`."""
         d, h = self.d_model, self.n_heads
@@ -157,7 +157,7 @@ class VATBlock(_HipModule):
             ops.linear_live_rows(x_rows, self._w(self.ca.in_proj_weight), self.ca.in_proj_bias, rows_dev, (d, 3 * d), tag="ca_kv_proj", out=kv[hw:])
         pair_src, pair_info = ops.bev_scene_pairs(row_src, B, n_tiles, hw)
         o = ops.attention_tiled_signed(qp, kv, row_src, pair_src, pair_info, totals, batch=B, n_heads=h, nq=nq, n_tiles=n_tiles,
-                                       dh=dh, scale=1.0 / math.sqrt(dh), shared_q=True, tag="ca_attn")
+                                       dh=dh, scale=1.0 / math.sqrt(dh), shared_q=True, tag="ca_attn", k_fp16=k_fp16)
         q2 = q2_1.unsqueeze(0).expand(B, nq, d).reshape(B * nq, d)
         y, _ = ops.linear(o, self._w(self.ca.out_proj.weight), self.ca.out_proj.bias, residual=q2, out_f32=True, tag="ca_out_proj")
         self._last_pair_info = pair_info                      # device tensor, read by bench / tests only
@@ -322,7 +322,7 @@ class VATLiDAR(_HipModule):
         keeps lo parts of K / V, which the tiled kernels do not carry)."""
         blk = self.blocks[0]
         return (C == 64 and H % 8 == 0 and W % 8 == 0 and self.d_model in (256, 512, 768, 1024) and blk.d_model // blk.n_heads == 64
-                and self._mode() in ("bf16", "mixed") and ops.attention_stream_ok(self.n_queries, H * W, 64)
+                and self._mode() in ("bf16", "mixed", "mixed16") and ops.attention_stream_ok(self.n_queries, H * W, 64)
                 and not os.environ.get("LVQ_NO_TILED_STREAM"))
 
     def _pe_tiled(self, H: int, W: int, dev) -> torch.Tensor:
@@ -369,6 +369,11 @@ class VATLiDAR(_HipModule):
         c0 = float(rr[C, C] ** 2)
         gam, bet = f64(self.norm_tokens.weight), self.norm_tokens.bias.detach().float().view(1, d).contiguous()
         a_pe = ops.cast(ops.scale_add_rows(self._pe_tiled(H, W, dev), bet), split)  # beta + PE[key], the A operand of the table GEMM
+        # |LayerNorm(y)_n| <= sqrt(d) whatever the input, so |x_n| <= sqrt(d) |gamma_n| + |beta_n| + max_key |PE_n| and every K entry of
+        # layer 0 is bounded by its weight row's L1 product with that: the static guarantee behind the fp16 K half of "mixed16"
+        xmax = (math.sqrt(d) * gam.abs() + f64(self.norm_tokens.bias).abs() + self._pe_tiled(H, W, dev).abs().amax(0).double().cpu())
+        wk0, bk0 = f64(self.blocks[0].ca.in_proj_weight)[d:2 * d], f64(self.blocks[0].ca.in_proj_bias)[d:2 * d]
+        k_bound = float((wk0.abs() @ xmax + bk0.abs()).max())
         layers = []
         for blk in self.blocks:
             blk.precision = self.precision
@@ -377,19 +382,19 @@ class VATLiDAR(_HipModule):
             m0 = (wkv @ (gam * bc)).float().contiguous().to(dev)
             t_tab, _ = ops.linear(a_pe, blk._w(blk.ca.in_proj_weight), blk.ca.in_proj_bias, out_f32=True, w_rows=(d, 3 * d))
             layers.append((m_bf, m0, t_tab))
-        fold = (r_bf, r0, c0, layers)
+        fold = (r_bf, r0, c0, layers, k_bound)
         self._pe_cache[key] = (ver, fold)
         return fold
 
-    def _tile_kv(self, li: int, feat, idx, live, dirty, counts, cap_rows, batch, H, W, out) -> None:
+    def _tile_kv(self, li: int, feat, idx, live, dirty, counts, cap_rows, batch, H, W, out, k_fp16: bool = False) -> None:
         C = feat.shape[1]
-        r_bf, r0, c0, layers = self._kv_fold(C, H, W, feat.device)
+        r_bf, r0, c0, layers, _ = self._kv_fold(C, H, W, feat.device)
         m_bf, m0, t_tab = layers[li]
         ops.bev_tile_kv(feat, idx, live, dirty, counts, cap_rows, batch, H, W, self.refine[0].weight.detach().reshape(C, 9).contiguous(),
                         self.refine[0].bias, m_bf, m0, r_bf, r0, c0, self.d_model, self.norm_tokens.eps, t_tab, out, tag="bev_kv",
-                        split_launch=not os.environ.get("LVQ_KV_ONE_LAUNCH"))
+                        split_launch=k_fp16 or not os.environ.get("LVQ_KV_ONE_LAUNCH"), k_fp16=k_fp16)
 
-    def _kv_buffers(self, C: int, H: int, W: int, dev, batch: int) -> List[torch.Tensor]:
+    def _kv_buffers(self, C: int, H: int, W: int, dev, batch: int, k16: bool = False) -> List[torch.Tensor]:
         """Per layer ONE K|V buffer [HW + batch*HW, 2d] bf16.  Rows 0 .. HW-1: the per-model TABLE = K|V of the EMPTY scene by the same
         kernel that serves the dirty rows (every cell forced dirty; key order = tile-major), cached per weights version and precision
         mode -- input-independent like the positional table.  Rows HW ..: the step's computed rows (capacity for `batch` scenes)."""
@@ -398,7 +403,7 @@ class VATLiDAR(_HipModule):
         for blk in self.blocks:
             params += [blk.ca.in_proj_weight, blk.ca.in_proj_bias]
         fused = not os.environ.get("LVQ_NO_FUSED_KV")
-        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(), fused)
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(), fused, k16)
         key = ("kv_buffer", H, W, dev)
         hw, d = H * W, self.d_model
         rows = hw + batch * hw
@@ -422,26 +427,41 @@ class VATLiDAR(_HipModule):
             blk.precision = self.precision
             buf = torch.empty((rows, 2 * d), dtype=torch.bfloat16, device=dev)
             if fused:
-                self._tile_kv(li, feat, idx, live, dirty, counts, hw, 1, H, W, buf[:hw])
+                self._tile_kv(li, feat, idx, live, dirty, counts, hw, 1, H, W, buf[:hw], k_fp16=k16 and li == 0)
             else:
                 ops.linear_live_rows(x, blk._w(blk.ca.in_proj_weight), blk.ca.in_proj_bias, counts[2:], (d, 3 * d), out=buf[:hw])
             bufs.append(buf)
         self._pe_cache[key] = (ver, bufs)
         return bufs
 
-    def _signed_totals(self, blk: "VATBlock", qp: BF, kv: torch.Tensor, H: int, W: int, dev) -> torch.Tensor:
+    def _q16_ok(self, blk: "VATBlock", qp: BF) -> bool:
+        """mixed16: the scaled queries of block 0 fit fp16 (they depend on the weights only: checked once per weights version)."""
+        params = [self.query, self.view_embed, blk.sa_ln.weight, blk.sa_ln.bias, blk.sa.in_proj_weight, blk.sa.in_proj_bias, blk.sa.out_proj.weight,
+                  blk.sa.out_proj.bias, blk.ca_ln.weight, blk.ca_ln.bias, blk.ca.in_proj_weight, blk.ca.in_proj_bias]
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(),)
+        hit = self._pe_cache.get("q16_ok")
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        dh = blk.d_model // blk.n_heads
+        qmax = float(ops.to_f32(qp).abs().max()) * (1.0 / math.sqrt(dh)) * 1.4426950408889634
+        ok = qmax < 3.0e4
+        self._pe_cache["q16_ok"] = (ver, ok)
+        return ok
+
+    def _signed_totals(self, blk: "VATBlock", qp: BF, kv: torch.Tensor, H: int, W: int, dev, k_fp16: bool = False) -> torch.Tensor:
         """Softmax sums of block 0's (scene-independent) cross-attention queries over ALL keys of the K|V table -> fp32
         [heads, nq, 66]; input-independent like the table itself, cached per weights version.  `qp` is this step's Q projection:
         the cached totals belong to exactly these bits as long as the version key is unchanged."""
         params = [self.query, self.view_embed, blk.sa_ln.weight, blk.sa_ln.bias, blk.sa.in_proj_weight, blk.sa.in_proj_bias, blk.sa.out_proj.weight,
                   blk.sa.out_proj.bias, blk.ca_ln.weight, blk.ca_ln.bias, blk.ca.in_proj_weight, blk.ca.in_proj_bias]
-        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(), kv.data_ptr())
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(), kv.data_ptr(), k_fp16)
         key = ("signed_totals", H, W, dev)
         hit = self._pe_cache.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
         dh = blk.d_model // blk.n_heads
-        tot = ops.attention_stream_totals(qp, kv[:H * W], n_heads=blk.n_heads, nq=self.n_queries, nkv=H * W, dh=dh, scale=1.0 / math.sqrt(dh))
+        tot = ops.attention_stream_totals(qp, kv[:H * W], n_heads=blk.n_heads, nq=self.n_queries, nkv=H * W, dh=dh, scale=1.0 / math.sqrt(dh),
+                                          k_fp16=k_fp16)
         self._pe_cache[key] = (ver, tot)
         return tot
 
@@ -460,22 +480,28 @@ class VATLiDAR(_HipModule):
                                           self.refine[0].weight.detach().reshape(C, 9).contiguous(), self.refine[0].bias, self._split())
             return self._decode(self._tokens_to_model(t, H, W, dev), batch, H, W)
         nt = (H // 8) * (W // 8)
-        kvs = self._kv_buffers(C, H, W, dev, batch)
+        fused = not os.environ.get("LVQ_NO_FUSED_KV")          # K|V straight from the conv token (k_tile_kv) vs tokens -> K|V GEMM
+        signed = not all_tiles_live and not os.environ.get("LVQ_NO_SIGNED_STREAM")
+        q2_1 = qp = None
+        k16 = False
+        if signed:
+            # block 0: the queries are the same for every scene -> query side once, attention over the dirty rows only
+            self.blocks[0].precision = self.precision
+            q2_1, qp = self.blocks[0].shared_query_side(self._queries(1), self.n_queries)
+            # "mixed16": fp16 Q K^T in block 0 when K (static bound from the fold) and the scaled Q provably fit fp16
+            k16 = (self._mode() == "mixed16" and fused and self._kv_fold(C, H, W, dev)[4] < 3.0e4 and self._q16_ok(self.blocks[0], qp))
+        kvs = self._kv_buffers(C, H, W, dev, batch, k16)
         idx = ops.pillar_index_map(coords_bzyx, n_live, batch, H, W)
         live, dirty, src, counts = ops.bev_tiles(idx, batch, H, W, dev, H * W, force_all=all_tiles_live)
-        fused = not os.environ.get("LVQ_NO_FUSED_KV")          # K|V straight from the conv token (k_tile_kv) vs tokens -> K|V GEMM
         x_live = None if fused else self._tile_tokens(feat, idx, live, dirty, counts, batch * nt * 64, batch, H, W)
-        signed = not all_tiles_live and not os.environ.get("LVQ_NO_SIGNED_STREAM")
         q2 = None if signed else self._queries(batch)
         for li, (blk, table) in enumerate(zip(self.blocks, kvs)):
             blk.precision = self.precision
             if fused:
-                self._tile_kv(li, feat, idx, live, dirty, counts, batch * nt * 64, batch, H, W, table[H * W:])
+                self._tile_kv(li, feat, idx, live, dirty, counts, batch * nt * 64, batch, H, W, table[H * W:], k_fp16=k16 and li == 0)
             if li == 0 and signed:
-                # block 0: the queries are the same for every scene -> query side once, attention over the live pieces only
-                q2_1, qp = blk.shared_query_side(self._queries(1), self.n_queries)
-                totals = self._signed_totals(blk, qp, table, H, W, dev)
-                q2 = blk.forward_tokens_tiled_signed(q2_1, qp, totals, x_live, table, src, counts[2:], batch, self.n_queries, nt)
+                totals = self._signed_totals(blk, qp, table, H, W, dev, k_fp16=k16)
+                q2 = blk.forward_tokens_tiled_signed(q2_1, qp, totals, x_live, table, src, counts[2:], batch, self.n_queries, nt, k_fp16=k16)
             else:
                 q2 = blk.forward_tokens_tiled(q2, x_live, table, src, counts[2:], batch, self.n_queries, nt)
         self._last_tile_counts = counts                       # device tensor (live pieces, their rows, dirty rows): read by bench / tests only

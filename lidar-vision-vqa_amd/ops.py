@@ -20,7 +20,7 @@ from . import _ffi as F
 
 BF = Tuple[torch.Tensor, Optional[torch.Tensor]]
 
-PRECISIONS = ("bf16", "bf16x3", "mixed")
+PRECISIONS = ("bf16", "bf16x3", "mixed", "mixed16")
 _default_precision = os.environ.get("LVQ_PRECISION", "bf16x3")
 assert _default_precision in PRECISIONS
 
@@ -268,7 +268,7 @@ def bev_tile_tokens(feat: torch.Tensor, idx: torch.Tensor, live: torch.Tensor, d
 
 def bev_tile_kv(feat: torch.Tensor, idx: torch.Tensor, live: torch.Tensor, dirty: torch.Tensor, counts: torch.Tensor, cap_rows: int, batch: int, ny: int,
                 nx: int, w9: torch.Tensor, b9: Optional[torch.Tensor], m: BF, m0: torch.Tensor, r: BF, r0: torch.Tensor, c0: float, d_ln: int, eps: float,
-                t_tiled: torch.Tensor, out: torch.Tensor, tag: Optional[str] = None, split_launch: bool = True) -> torch.Tensor:
+                t_tiled: torch.Tensor, out: torch.Tensor, tag: Optional[str] = None, split_launch: bool = True, k_fp16: bool = False) -> torch.Tensor:
     """K|V rows of the dirty cells straight from the pillar features (lvq_bev_tile_kv: LayerNorm and the K|V projection folded onto the
     64-channel conv token) -> `out` [>= cap_rows, 2n] plain bf16, rows 0 .. counts[2]-1 written."""
     F.require_cuda(feat, idx, live, dirty, counts, w9, b9, m0, r0, t_tiled, out)
@@ -288,7 +288,7 @@ def bev_tile_kv(feat: torch.Tensor, idx: torch.Tensor, live: torch.Tensor, dirty
     with region(tag, feat.device):
         rc = L.lvq_bev_tile_kv(F.ptr(feat), F.ptr(idx), F.ptr(live), F.ptr(dirty), F.ptr(counts), F.i64(cap_tiles), F.cint(batch),
                                F.cint(ny), F.cint(nx), F.cint(feat.shape[1]), F.ptr(w9), F.ptr(b9), F.ptr(m[0]), F.ptr(m[1]), F.ptr(m0), F.ptr(r[0]),
-                               F.ptr(r[1]), F.ptr(r0), F.cfloat(c0), F.cint(d_ln), F.cfloat(eps), F.ptr(t_tiled), F.cint(n2 // 2), F.ptr(out),
+                               F.ptr(r[1]), F.ptr(r0), F.cfloat(c0), F.cint(d_ln), F.cfloat(eps), F.ptr(t_tiled), F.cint(n2 // 2), F.cint(1 if k_fp16 else 0), F.ptr(out),
                                F.ptr(ws), F.csize(ws.numel() if ws is not None else 0), F.stream_ptr(feat.device))
     F.check(rc, "lvq_bev_tile_kv")
     return out
@@ -321,7 +321,7 @@ def linear_live_rows(a: BF, w: BF, bias: Optional[torch.Tensor], rows_dev: torch
 
 
 def attention_tiled(q: BF, kv: torch.Tensor, row_src: torch.Tensor, *, batch: int, n_heads: int, nq: int, n_tiles: int, dh: int, scale: float,
-                    tag: Optional[str] = None) -> BF:
+                    tag: Optional[str] = None, k_fp16: bool = False) -> BF:
     """q BF [batch*nq, d]; kv [rows, 2d] plain bf16 (K | V packed): the per-model table rows and every batch's computed rows in ONE buffer;
     row_src [batch, n_tiles*64] i32 = the row of every key slot -> BF [batch*nq, d]."""
     qh, ql = q
@@ -334,7 +334,8 @@ def attention_tiled(q: BF, kv: torch.Tensor, row_src: torch.Tensor, *, batch: in
     with region(tag, dev):
         rc = L.lvq_attention_bf16_tiled(F.ptr(qh), F.ptr(ql), F.ptr(kv), F.ptr(kv[:, d:]), F.ptr(row_src), F.cint(batch), F.cint(n_heads), F.cint(nq),
                                         F.cint(n_tiles), F.cint(dh), F.i64(nq * d), F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.i64(nq * d), F.i64(d),
-                                        F.i64(dh), F.cfloat(scale), F.ptr(oh), F.ptr(ol), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
+                                        F.i64(dh), F.cfloat(scale), F.cint(1 if k_fp16 else 0), F.ptr(oh), F.ptr(ol), F.ptr(ws), F.csize(ws.numel()),
+                                        F.stream_ptr(dev))
     F.check(rc, f"lvq_attention_bf16_tiled (B={batch}, H={n_heads}, nq={nq}, tiles={n_tiles})")
     return oh, ol
 
@@ -348,7 +349,7 @@ def _att_ws(dev, nbytes: int) -> torch.Tensor:
     return ws
 
 
-def attention_stream_totals(q: BF, kv: torch.Tensor, *, n_heads: int, nq: int, nkv: int, dh: int, scale: float) -> torch.Tensor:
+def attention_stream_totals(q: BF, kv: torch.Tensor, *, n_heads: int, nq: int, nkv: int, dh: int, scale: float, k_fp16: bool = False) -> torch.Tensor:
     """Unnormalised softmax sums (O | m | l) of ONE batch of queries q BF [nq, d] over the dense key stream kv [nkv, 2d] (K | V packed,
     plain bf16) -> fp32 [n_heads, nq, dh + 2]: the per-model totals of attention_tiled_signed."""
     qh, ql = q
@@ -361,7 +362,7 @@ def attention_stream_totals(q: BF, kv: torch.Tensor, *, n_heads: int, nq: int, n
     ws = _att_ws(dev, nbytes)
     tot = torch.empty((n_heads, nq, dh + 2), dtype=torch.float32, device=dev)
     rc = L.lvq_attention_bf16_stream_totals(F.ptr(qh), F.ptr(ql), F.ptr(kv), F.ptr(kv[:, d:]), F.cint(n_heads), F.cint(nq), F.cint(nkv), F.cint(dh),
-                                            F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.cfloat(scale), F.ptr(tot), F.ptr(ws), F.csize(ws.numel()),
+                                            F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.cfloat(scale), F.cint(1 if k_fp16 else 0), F.ptr(tot), F.ptr(ws), F.csize(ws.numel()),
                                             F.stream_ptr(dev))
     F.check(rc, f"lvq_attention_bf16_stream_totals (H={n_heads}, nq={nq}, nkv={nkv})")
     return tot
@@ -379,7 +380,7 @@ def bev_scene_pairs(row_src: torch.Tensor, batch: int, n_tiles: int, row_base: i
 
 
 def attention_tiled_signed(q: BF, kv: torch.Tensor, row_src: torch.Tensor, pair_src: torch.Tensor, pair_info: torch.Tensor, totals: torch.Tensor, *, batch: int, n_heads: int, nq: int, n_tiles: int, dh: int, scale: float,
-                           shared_q: bool, tag: Optional[str] = None) -> BF:
+                           shared_q: bool, tag: Optional[str] = None, k_fp16: bool = False) -> BF:
     """attention_tiled over the dirty rows only (queries independent of the batch; `totals` from attention_stream_totals with the
     SAME q over the table rows kv[:n_tiles*64]).  q BF [nq, d] when shared_q else [batch*nq, d] (identical per batch) -> BF [batch*nq, d]."""
     qh, ql = q
@@ -395,7 +396,7 @@ def attention_tiled_signed(q: BF, kv: torch.Tensor, row_src: torch.Tensor, pair_
         rc = L.lvq_attention_bf16_tiled_signed(F.ptr(qh), F.ptr(ql), F.ptr(kv), F.ptr(kv[:, d:]), F.ptr(row_src), F.ptr(pair_src), F.ptr(pair_info), F.cint(pair_src.shape[1]), F.ptr(totals),
                                                F.cint(batch), F.cint(n_heads), F.cint(nq), F.cint(n_tiles), F.cint(dh),
                                                F.i64(0 if shared_q else nq * d), F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.i64(nq * d), F.i64(d),
-                                               F.i64(dh), F.cfloat(scale), F.ptr(oh), F.ptr(ol), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
+                                               F.i64(dh), F.cfloat(scale), F.cint(1 if k_fp16 else 0), F.ptr(oh), F.ptr(ol), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
     F.check(rc, f"lvq_attention_bf16_tiled_signed (B={batch}, H={n_heads}, nq={nq}, tiles={n_tiles})")
     return oh, ol
 

@@ -375,7 +375,34 @@ def test_fused_kv_kernel_matches_token_kernel_plus_gemm(prec, monkeypatch):
     assert float((a["lidar_tokens"] - b["lidar_tokens"]).abs().max()) < tol
 
 
-@pytest.mark.parametrize("prec,tol", [("mixed", 2e-3), ("bf16", None)])
+def test_attention_tiled_signed_fp16_qk():
+    """k_fp16: the K half of the buffer holds IEEE fp16, q is rounded once to fp16 and Q K^T is one fp16 MFMA pass -- against the Q-split
+    bf16 form on the same (fp16-representable) keys: equal up to the 2^-11 rounding of q."""
+    o = ops()
+    B, H, nq, n_tiles = 3, 4, 576, 128
+    d = H * 64
+    hw = n_tiles * 64
+    kv, src, _ = _row_case(B, H, n_tiles, [0.3, 0.45, 0.8], 29)
+    k16 = kv[:, :d].float().half()                                # keys that both formats hold exactly: fp16 values with 8-bit significands
+    kq = k16.float().bfloat16()
+    kv_b = kv.clone(); kv_b[:, :d] = kq                           # bf16 view of the same numbers
+    kv_h = kv.clone(); kv_h[:, :d] = kq.float().half().view(torch.bfloat16)      # ... and their fp16 bit patterns
+    qb = _shared_q(o, H, nq, 30)
+    ref, _ = _signed(o, qb, kv_b, src, B, H, nq, n_tiles)
+    srcd = src.to(DEV).contiguous()
+    pair_src, pair_info = o.bev_scene_pairs(srcd, B, n_tiles, hw)
+    tot = o.attention_stream_totals(qb, kv_h[:hw], n_heads=H, nq=nq, nkv=hw, dh=64, scale=1.0 / 8.0, k_fp16=True)
+    got = o.attention_tiled_signed(qb, kv_h, srcd, pair_src, pair_info, tot, batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=64, scale=1.0 / 8.0,
+                                   shared_q=True, k_fp16=True)
+    g32, r32 = o.to_f32(got), o.to_f32(ref)
+    err = float((g32 - r32).abs().max())
+    assert 0 < err < 3e-3 * max(float(r32.abs().max()), 1.0), err
+    full = o.attention_tiled((qb[0].repeat(B, 1), qb[1].repeat(B, 1)), kv_h, srcd, batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=64, scale=1.0 / 8.0,
+                             k_fp16=True)
+    assert float((o.to_f32(full) - g32).abs().max()) < 2e-5 * max(float(r32.abs().max()), 1.0)
+
+
+@pytest.mark.parametrize("prec,tol", [("mixed", 2e-3), ("mixed16", 3e-3), ("bf16", None)])
 def test_tiled_route_vs_oracle(prec, tol):
     """Small-grid pipeline through the tiled route against the CPU oracle.  16 384 keys average the per-key roundings 4x less
     than the 262 144 of the bench workload, hence 2e-3 here; the full-size run (test_gpu_pipeline) holds the north-star 1e-3."""

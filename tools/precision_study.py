@@ -127,6 +127,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1100)
     ap.add_argument("--only-mixed", action="store_true", help="skip the per-group table")
+    ap.add_argument("--only-q16", action="store_true", help="only the fp16-Q candidate (stream plain bf16, Q single fp16, K fp16)")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 1)
     torch.set_grad_enabled(False)
@@ -167,6 +168,14 @@ def main():
         return out, lt, time.time() - t0
 
     ref, ref_lt, dt = run([])
+    if args.only_q16:
+        F16.update(["lidar.ca.q"])
+        out, lt, dt = run(RANDOM_PER_KEY)
+        F16.clear()
+        print(f"seed {args.seed}: stream bf16, Q single fp16: fused err {(out - ref).abs().max().item():.3e} (|ref| max {ref.abs().max():.3f})", flush=True)
+        out, lt, dt = run(RANDOM_PER_KEY)
+        print(f"seed {args.seed}: stream bf16, Q exact (= mixed):  fused err {(out - ref).abs().max().item():.3e}", flush=True)
+        return
     print(f"reference: fused absmax {ref.abs().max():.4f}, lidar tokens absmax {ref_lt.abs().max():.4f}  ({dt:.1f} s)", flush=True)
     rows = []
     for gname in ([] if args.only_mixed else GROUPS):
