@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     const float cexp0 = a.scale * 1.4426950408889634f;
 
     // Q^T fragments, pre-multiplied by scale * log2(e): lane supplies Q[qi][16 ks + 8 hi .. +7]
-    bf16x8 qf[4], qfl[QS == 1 ? 4 : 1];
+    bf16x8 qf[4], qfl[(QS == 1 || QS == 3) ? 4 : 1];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         uint4 v = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
@@ -585,7 +585,13 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
         uint32_t *w = reinterpret_cast<uint32_t *>(&v), *wl = reinterpret_cast<uint32_t *>(&vl);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            if (QS == 2) {      // (hi + lo) * c in fp32 -> fp16 (round to nearest even)
+            if (QS == 3) {      // fp16 hi + fp16 lo (22 bits) against fp16 K: the per-model totals of the mixed16 mode
+                const float x0 = (__uint_as_float(w[e] << 16) + __uint_as_float(wl[e] << 16)) * cexp0;
+                const float x1 = (__uint_as_float(w[e] & 0xffff0000u) + __uint_as_float(wl[e] & 0xffff0000u)) * cexp0;
+                const f16x2_t hh = {(_Float16)x0, (_Float16)x1};
+                w[e] = __builtin_bit_cast(uint32_t, hh);
+                wl[e] = pack_f16(x0 - (float)hh[0], x1 - (float)hh[1]);
+            } else if (QS == 2) {      // (hi + lo) * c in fp32 -> fp16 (round to nearest even)
                 const float x0 = (__uint_as_float(w[e] << 16) + __uint_as_float(wl[e] << 16)) * cexp0;
                 const float x1 = (__uint_as_float(w[e] & 0xffff0000u) + __uint_as_float(wl[e] & 0xffff0000u)) * cexp0;
                 w[e] = pack_f16(x0, x1);
@@ -600,7 +606,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
             }
         }
         qf[ks] = *reinterpret_cast<bf16x8 *>(&v);
-        if (QS == 1) qfl[ks] = *reinterpret_cast<bf16x8 *>(&vl);
+        if (QS == 1 || QS == 3) qfl[ks] = *reinterpret_cast<bf16x8 *>(&vl);
     }
     f32x16 o[2];
 #pragma unroll
@@ -725,9 +731,10 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + (kb * 32 + l31) * KROW + (((2 * ks + hi) ^ fk) << 3));
-                if (QS == 2) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qf[ks]), sc[kb], 0, 0, 0);
+                if (QS >= 2) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qf[ks]), sc[kb], 0, 0, 0);
                 else         sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kb], 0, 0, 0);
                 if (QS == 1) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[ks], sc[kb], 0, 0, 0);
+                if (QS == 3) sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qfl[ks]), sc[kb], 0, 0, 0);
             }
         }
     };
@@ -793,9 +800,10 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + (kb * 32 + l31) * KROW + (((2 * ks + hi) ^ fk) << 3));
-                if (QS == 2) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qf[ks]), sc, 0, 0, 0);
+                if (QS >= 2) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qf[ks]), sc, 0, 0, 0);
                 else         sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc, 0, 0, 0);
                 if (QS == 1) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qfl[ks], sc, 0, 0, 0);
+                if (QS == 3) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf), __builtin_bit_cast(f16x8, qfl[ks]), sc, 0, 0, 0);
             }
             // rows rb + {0, 8} (step 0) and rb + {16, 24} (step 1) of this 32-key block: byte immediates (32 kb + 8 j) * 128
             bf16x4 a00, a01, a10, a11, b00, b01, b10, b11;
@@ -1381,7 +1389,13 @@ extern "C" int lvq_attention_bf16_stream_totals(const lvq_bf16 *q, const lvq_bf1
     hipStream_t st = lvq_s(stream);
     const size_t lds = K32_LDS;
     const int64_t ngrp = (int64_t)a.H * a.nsplit;
-    launch_k32<0>(a, pl.k32, k_fp16 ? 2 : (q_lo != nullptr ? 1 : 0), (ngrp + 7) / 8 * 8 * a.nqt, lds, st);
+    if (k_fp16 == 2) {       // fp16 K against the query as fp16 hi + lo: the totals keep the full query, only the per-batch streams round it
+        const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;
+        if (pl.k32 == 6) hipLaunchKernelGGL((k_attn32<6, 3, 0>), dim3((unsigned)nwg), dim3(384), lds, st, a);
+        else             hipLaunchKernelGGL((k_attn32<4, 3, 0>), dim3((unsigned)nwg), dim3(256), lds, st, a);
+    } else {
+        launch_k32<0>(a, pl.k32, k_fp16 ? 2 : (q_lo != nullptr ? 1 : 0), (ngrp + 7) / 8 * 8 * a.nqt, lds, st);
+    }
     const int64_t total = (int64_t)a.H * a.Nq * (a.dh / 4);
     hipLaunchKernelGGL(k_attn_combine_raw, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a, totals);
     return lvq_launch_status();

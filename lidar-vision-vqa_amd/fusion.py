@@ -460,8 +460,10 @@ class VATLiDAR(_HipModule):
         if hit is not None and hit[0] == ver:
             return hit[1]
         dh = blk.d_model // blk.n_heads
+        # mixed16: the totals keep the full query (fp16 hi + lo against the fp16 table keys, k_fp16 = 2) unless LVQ_TOTALS_Q16 asks for the
+        # once-rounded query of the per-scene streams
         tot = ops.attention_stream_totals(qp, kv[:H * W], n_heads=blk.n_heads, nq=self.n_queries, nkv=H * W, dh=dh, scale=1.0 / math.sqrt(dh),
-                                          k_fp16=k_fp16)
+                                          k_fp16=(1 if os.environ.get("LVQ_TOTALS_Q16") else 2) if k_fp16 else 0)
         self._pe_cache[key] = (ver, tot)
         return tot
 

@@ -349,7 +349,7 @@ def _att_ws(dev, nbytes: int) -> torch.Tensor:
     return ws
 
 
-def attention_stream_totals(q: BF, kv: torch.Tensor, *, n_heads: int, nq: int, nkv: int, dh: int, scale: float, k_fp16: bool = False) -> torch.Tensor:
+def attention_stream_totals(q: BF, kv: torch.Tensor, *, n_heads: int, nq: int, nkv: int, dh: int, scale: float, k_fp16: int = 0) -> torch.Tensor:
     """Unnormalised softmax sums (O | m | l) of ONE batch of queries q BF [nq, d] over the dense key stream kv [nkv, 2d] (K | V packed,
     plain bf16) -> fp32 [n_heads, nq, dh + 2]: the per-model totals of attention_tiled_signed."""
     qh, ql = q
@@ -362,7 +362,7 @@ def attention_stream_totals(q: BF, kv: torch.Tensor, *, n_heads: int, nq: int, n
     ws = _att_ws(dev, nbytes)
     tot = torch.empty((n_heads, nq, dh + 2), dtype=torch.float32, device=dev)
     rc = L.lvq_attention_bf16_stream_totals(F.ptr(qh), F.ptr(ql), F.ptr(kv), F.ptr(kv[:, d:]), F.cint(n_heads), F.cint(nq), F.cint(nkv), F.cint(dh),
-                                            F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.cfloat(scale), F.cint(1 if k_fp16 else 0), F.ptr(tot), F.ptr(ws), F.csize(ws.numel()),
+                                            F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.cfloat(scale), F.cint(int(k_fp16)), F.ptr(tot), F.ptr(ws), F.csize(ws.numel()),
                                             F.stream_ptr(dev))
     F.check(rc, f"lvq_attention_bf16_stream_totals (H={n_heads}, nq={nq}, nkv={nkv})")
     return tot

@@ -112,8 +112,9 @@ def test_pipeline_mixed_mode_meets_the_bar_at_full_size():
     err_bf16 = (pipe(pts, off, patches)["fused"].cpu() - ref["fused"]).abs().max().item()
     assert err_bf16 > 10 * err, (err_bf16, err)
     # `mixed16`: block 0's Q K^T as ONE fp16 pass (Q rounded once to 11 bits, K stored as fp16) -- still inside the bar, with a third of the
-    # margin (tools/precision_study.py --only-q16 predicts 3.7e-4); the guards that allow it (static |K| bound, |Q| check) must hold here
+    # margin: the per-model totals keep the full query, so only the dirty cells' share of the keys sees the rounded one (5.6e-4 -> 2.9e-4);
+    # the guards that allow the mode (static |K| bound, |Q| check) must hold here
     pipe.set_precision("mixed16")
     out16 = pipe(pts, off, patches)
     err16 = (out16["fused"].cpu() - ref["fused"]).abs().max().item()
-    assert err16 < 1e-3 and err < err16 < 6e-4, (err16, err)
+    assert err16 < 1e-3 and err < err16 < 4.5e-4, (err16, err)
