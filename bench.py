@@ -326,7 +326,7 @@ def main():
     }
 
     mode_values = {args.precision: round(value, 1)}
-    if not args.no_extras:
+    if not args.no_extras and world == 1:                 # secondary measurements: single-GPU runs only (N > 1 prints the scaling line and leaves)
         # ---- per-stage event times of the cross-attention sub-path in the timed region ----
         result["stage_ms"] = {k: {"mean": round(avg_ms(v), 4), "max": round(max(a.elapsed_time(b) for a, b in v), 4),
                                   "min": round(min(a.elapsed_time(b) for a, b in v), 4), "launches_per_step": len(v) // args.steps}
