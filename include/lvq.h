@@ -253,12 +253,15 @@ int lvq_bev_tile_tokens(const float *pillar_feat, const int32_t *idx_map, const 
  * m_lo / r_lo != NULL: t, M and R as hi + lo (three products).  kv [dirty rows, 2 n] bf16: the compact rows numbered by lvq_bev_tiles.
  * ws != NULL (lvq_bev_tile_kv_workspace_bytes(cap_tiles)): two launches -- k_conv_rows stores (t, rstd, key) of the dirty rows, k_kv_rows
  * projects contiguous 64-row tiles -- instead of the single kernel; the same arithmetic, bit-identical rows.  k_fp16 != 0 (two-launch
- * form only): the K half (columns 0 .. n-1) is stored as IEEE fp16 for the fp16 Q K^T pass of the attention entry points. */
+ * form only): the K half (columns 0 .. n-1) is stored as IEEE fp16 for the fp16 Q K^T pass of the attention entry points.
+ * t_f16 != 0 (two-launch form only): t_tiled holds IEEE fp16 instead of fp32 (half the bytes of the kernel's largest read stream; the
+ * caller guarantees |T| < 65504 -- its rounding, 2^-12, disappears under the bf16 rounding of the rows). */
 size_t lvq_bev_tile_kv_workspace_bytes(int64_t cap_tiles);
 int lvq_bev_tile_kv(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *piece_dirty,
                     const int32_t *counts, int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9,
                     const lvq_bf16 *m, const lvq_bf16 *m_lo, const float *m0, const lvq_bf16 *r, const lvq_bf16 *r_lo, const float *r0, float c0,
-                    int d_ln, float eps, const float *t_tiled, int n, int k_fp16, lvq_bf16 *kv, void *ws, size_t ws_bytes, lvq_stream_t stream);
+                    int d_ln, float eps, const void *t_tiled, int t_f16, int n, int k_fp16, lvq_bf16 *kv, void *ws, size_t ws_bytes,
+                    lvq_stream_t stream);
 /* c[0 .. *m_rows_dev) = a @ w^T + bias over the live rows only (the row count stays on the device); m_cap, n multiples of 256,
  * k of 64.  Operand forms as lvq_gemm_bf16 (plain | a plain, w hi + lo | both hi + lo). */
 int lvq_gemm_bf16_live_rows(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,

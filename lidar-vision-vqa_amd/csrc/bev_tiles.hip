@@ -1044,7 +1044,10 @@ struct KvRowArgs {
     int k_fp16;
 };
 
-template <int J, bool X3>
+// TH: the table T is IEEE fp16 (its values are bounded by the fold; the rounding, 2^-12, disappears under the bf16 rounding of the result):
+// half the L2 traffic of the kernel's largest stream.  A lane then owns 8 consecutive columns per PAIR of column tiles, so one 16-byte
+// request still covers a full 64-byte line per cell.
+template <int J, bool X3, bool TH>
 __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
     constexpr int N = 128 * J, C = 64, JH = J / 2;
     static_assert(J % 2 == 0, "even J");
@@ -1078,7 +1081,8 @@ __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
     bf16x8 wf[J][2], wfl[X3 ? J : 1][2];
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-        const int n = ncol0 + 16 * J * wid + 16 * j + l15;            // column tile j of this wave, A row m = l15 -> column 16 j + m
+        // column tile j of this wave, A row m = l15 -> column 16 j + m (fp32 T) or 32 (j / 2) + 8 (m / 4) + 4 (j % 2) + m % 4 (fp16 T)
+        const int n = ncol0 + 16 * J * wid + (TH ? 32 * (j >> 1) + 8 * (l15 >> 2) + 4 * (j & 1) + (l15 & 3) : 16 * j + l15);
         wf[j][0] = *reinterpret_cast<const bf16x8 *>(a.mh + (int64_t)n * C + 8 * g4);
         wf[j][1] = *reinterpret_cast<const bf16x8 *>(a.mh + (int64_t)n * C + 32 + 8 * g4);
         if (X3) {
@@ -1089,7 +1093,8 @@ __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
     // C layout: lane (cell = l15, g4) holds rows 4 g4 .. 4 g4 + 3 of every column tile, i.e. columns 16 J w + 16 j + 4 g4 + r: for a
     // fixed j the four g4 lanes of a cell cover 64 CONTIGUOUS bytes of its T row (one full line per cell and request; with 4 J
     // consecutive columns per lane every request touched 64 different lines for 16 bytes each: 5.50 -> 5.17 ms)
-    const int col0 = 16 * J * wid + 4 * g4;
+    const int col0 = 16 * J * wid + (TH ? 8 : 4) * g4;
+    auto colj = [&](int j) { return TH ? 32 * (j >> 1) + 4 * (j & 1) : 16 * j; };      // lane's column of tile j, relative to col0
     // stage the 64 contiguous t rows of tile g: wave w moves rows 8 w .. 8 w + 7 (one 1-KiB LDS-DMA for hi, one for lo); LDS position
     // (row, chunk c) receives SOURCE chunk c ^ ((row >> 1) & 7), the swizzle the fragment reads expect.  Rows past the end are clamped.
     auto stage = [&](int64_t g, int buf) {
@@ -1120,7 +1125,7 @@ __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
 #pragma unroll
         for (int jj = 0; jj < JH; ++jj) {
             const int j = HF * JH + jj;
-            acc[jj] = *reinterpret_cast<const f32x4 *>(pb + 16 * j);
+            acc[jj] = *reinterpret_cast<const f32x4 *>(pb + colj(j));
             acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], th0, acc[jj], 0, 0, 0);
             acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], th1, acc[jj], 0, 0, 0);
             if (X3) {
@@ -1160,9 +1165,19 @@ __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
             valid = g * TCELLS + gq * 16 + l15 < n_rows;
             rs = gq == 0 ? rq[0] : gq == 1 ? rq[1] : gq == 2 ? rq[2] : rq[3];
             const int key = gq == 0 ? kq[0] : gq == 1 ? kq[1] : gq == 2 ? kq[2] : kq[3];
-            const float *tep = a.te + (int64_t)key * (2 * N) + ncol0 + col0;
+            if (TH) {                                               // 8 halfs (tiles 2 p, 2 p + 1) per request, kept packed until their use
+                const uint16_t *tep = reinterpret_cast<const uint16_t *>(a.te) + (int64_t)key * (2 * N) + ncol0 + col0;
 #pragma unroll
-            for (int jj = 0; jj < 2 * JH; ++jj) te[jj] = *reinterpret_cast<const f32x4 *>(tep + 16 * jj);
+                for (int p2 = 0; p2 < JH; ++p2) {
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(tep + 32 * p2);
+                    te[2 * p2] = f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), 0.f, 0.f};
+                    te[2 * p2 + 1] = f32x4{__uint_as_float(v[2]), __uint_as_float(v[3]), 0.f, 0.f};
+                }
+            } else {
+                const float *tep = a.te + (int64_t)key * (2 * N) + ncol0 + col0;
+#pragma unroll
+                for (int jj = 0; jj < 2 * JH; ++jj) te[jj] = *reinterpret_cast<const f32x4 *>(tep + 16 * jj);
+            }
         };
         auto emit = [&](int gq, const f32x4 (&te)[2 * JH], const float rs, const bool valid) {
             bf16x8 th0, th1, tl0, tl1;
@@ -1176,7 +1191,11 @@ __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
                 uint32_t oh[2 * JH];
 #pragma unroll
                 for (int jj = 0; jj < JH; ++jj) {
-                    const f32x4 tv = te[HF * JH + jj];
+                    f32x4 tv = te[HF * JH + jj];
+                    if (TH) {                                       // two packed half pairs -> four floats
+                        const f16x2_t h0 = __builtin_bit_cast(f16x2_t, __float_as_uint(tv[0])), h1 = __builtin_bit_cast(f16x2_t, __float_as_uint(tv[1]));
+                        tv = f32x4{(float)h0[0], (float)h0[1], (float)h1[0], (float)h1[1]};
+                    }
                     if (as_f16) {
                         oh[2 * jj] = pack_f16(acc[jj][0] * rs + tv[0], acc[jj][1] * rs + tv[1]);
                         oh[2 * jj + 1] = pack_f16(acc[jj][2] * rs + tv[2], acc[jj][3] * rs + tv[3]);
@@ -1187,7 +1206,7 @@ __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
                 }
 #pragma unroll
                 for (int jj = 0; jj < JH; ++jj)
-                    *reinterpret_cast<uint2 *>(dst + 16 * (HF * JH + jj)) = make_uint2(oh[2 * jj], oh[2 * jj + 1]);
+                    *reinterpret_cast<uint2 *>(dst + colj(HF * JH + jj)) = make_uint2(oh[2 * jj], oh[2 * jj + 1]);
             };
             half_out(std::integral_constant<int, 0>{});
             half_out(std::integral_constant<int, 1>{});
@@ -1263,15 +1282,22 @@ template <int J> static int launch_tile_kv(const bt::KvArgs &a, bool x3, int64_t
 
 // K|V rows of the dirty cells straight from the pillar features (k_tile_kv): refine conv + GELU -> t, then
 // kv = rstd (M t + m0) + T[key] with rstd = 1 / sqrt((|R t + r0|^2 + c0) / d_ln + eps).  n = d (the K and the V half are n columns each).
-template <int J> static int launch_kv_rows(const bt::KvRowArgs &a, bool x3, int64_t cap_tiles, hipStream_t st) {
+template <int J> static int launch_kv_rows(const bt::KvRowArgs &a, bool x3, bool t_f16, int64_t cap_tiles, hipStream_t st) {
     const size_t lds = (size_t)2 * 2 * bt::TCELLS * 64 * 2 + (size_t)128 * J * 4 + (size_t)2 * 16 * (128 * J + 8) * 2;
     static LvqLdsOnce once;
-    if (lds > 64 * 1024 && !lvq_ensure_lds(once, {(const void *)bt::k_kv_rows<J, false>, (const void *)bt::k_kv_rows<J, true>}, lds)) return LVQ_ELAUNCH;
+    if (lds > 64 * 1024 && !lvq_ensure_lds(once, {(const void *)bt::k_kv_rows<J, false, false>, (const void *)bt::k_kv_rows<J, true, false>,
+                                                   (const void *)bt::k_kv_rows<J, false, true>, (const void *)bt::k_kv_rows<J, true, true>}, lds))
+        return LVQ_ELAUNCH;
     int64_t grid = (int64_t)lvq_cu_count();
     if (grid > cap_tiles) grid = cap_tiles;
     grid *= 2;                                                   // two column halves (K, V) per tile
-    if (x3) hipLaunchKernelGGL((bt::k_kv_rows<J, true>), dim3((unsigned)grid), dim3(512), lds, st, a);
-    else    hipLaunchKernelGGL((bt::k_kv_rows<J, false>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    if (t_f16) {
+        if (x3) hipLaunchKernelGGL((bt::k_kv_rows<J, true, true>), dim3((unsigned)grid), dim3(512), lds, st, a);
+        else    hipLaunchKernelGGL((bt::k_kv_rows<J, false, true>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    } else {
+        if (x3) hipLaunchKernelGGL((bt::k_kv_rows<J, true, false>), dim3((unsigned)grid), dim3(512), lds, st, a);
+        else    hipLaunchKernelGGL((bt::k_kv_rows<J, false, false>), dim3((unsigned)grid), dim3(512), lds, st, a);
+    }
     return lvq_launch_status();
 }
 
@@ -1289,13 +1315,13 @@ extern "C" size_t lvq_bev_tile_kv_workspace_bytes(int64_t cap_tiles) {
 extern "C" int lvq_bev_tile_kv(const float *pillar_feat, const int32_t *idx_map, const int32_t *live_list, const int32_t *piece_dirty,
                                const int32_t *counts, int64_t cap_tiles, int batch, int ny, int nx, int c_in, const float *w9, const float *b9,
                                const lvq_bf16 *m, const lvq_bf16 *m_lo, const float *m0, const lvq_bf16 *r, const lvq_bf16 *r_lo, const float *r0,
-                               float c0, int d_ln, float eps, const float *t_tiled, int n, int k_fp16, lvq_bf16 *kv, void *ws, size_t ws_bytes,
-                               lvq_stream_t stream) {
+                               float c0, int d_ln, float eps, const void *t_tiled, int t_f16, int n, int k_fp16, lvq_bf16 *kv, void *ws,
+                               size_t ws_bytes, lvq_stream_t stream) {
     if (batch <= 0 || ny <= 0 || nx <= 0 || cap_tiles <= 0 || d_ln <= 0 || !idx_map || !live_list || !piece_dirty || !counts || !w9 || !m || !m0 || !r ||
         !r0 || !t_tiled || !kv)
         return LVQ_EINVAL;
     if ((m_lo == nullptr) != (r_lo == nullptr)) return LVQ_EINVAL;
-    if (k_fp16 && ws == nullptr) return LVQ_EUNSUPPORTED;          // the fp16 K half is a feature of the two-launch form
+    if ((k_fp16 || t_f16) && ws == nullptr) return LVQ_EUNSUPPORTED;          // fp16 K half / fp16 table: features of the two-launch form
     if (c_in != 64 || (ny % 8) || (nx % 8) || (n % 256) || n < 256 || n > 1024) return LVQ_EUNSUPPORTED;
     if (((uintptr_t)pillar_feat | (uintptr_t)m | (uintptr_t)m_lo | (uintptr_t)r | (uintptr_t)r_lo | (uintptr_t)m0 | (uintptr_t)r0 | (uintptr_t)t_tiled |
          (uintptr_t)kv) & 15)
@@ -1303,7 +1329,7 @@ extern "C" int lvq_bev_tile_kv(const float *pillar_feat, const int32_t *idx_map,
     bt::KvArgs a;
     a.feat = pillar_feat; a.idx = idx_map; a.live_list = live_list; a.piece_dirty = reinterpret_cast<const int2 *>(piece_dirty); a.counts = counts;
     a.w9 = w9; a.b9 = b9; a.mh = m; a.ml = m_lo; a.m0 = m0; a.rh = r; a.rl = r_lo; a.r0 = r0; a.c0 = c0; a.inv_d = 1.0f / (float)d_ln; a.eps = eps;
-    a.te = t_tiled; a.S = batch; a.H = ny; a.W = nx; a.out = kv;
+    a.te = static_cast<const float *>(t_tiled); a.S = batch; a.H = ny; a.W = nx; a.out = kv;
     hipStream_t st = lvq_s(stream);
     const bool x3 = m_lo != nullptr;
     if (ws != nullptr) {
@@ -1327,12 +1353,12 @@ extern "C" int lvq_bev_tile_kv(const float *pillar_feat, const int32_t *idx_map,
         if (x3) hipLaunchKernelGGL((bt::k_conv_rows<true>), dim3((unsigned)grid), dim3(512), lds, st, c);
         else    hipLaunchKernelGGL((bt::k_conv_rows<false>), dim3((unsigned)grid), dim3(512), lds, st, c);
         bt::KvRowArgs k;
-        k.th = th; k.tl = x3 ? tl : nullptr; k.rstd = rstd; k.key = key; k.n_rows = counts + 2; k.mh = m; k.ml = m_lo; k.m0 = m0; k.te = t_tiled; k.out = kv; k.k_fp16 = k_fp16;
+        k.th = th; k.tl = x3 ? tl : nullptr; k.rstd = rstd; k.key = key; k.n_rows = counts + 2; k.mh = m; k.ml = m_lo; k.m0 = m0; k.te = static_cast<const float *>(t_tiled); k.out = kv; k.k_fp16 = k_fp16;
         switch (n / 128) {
-            case 2: return launch_kv_rows<2>(k, x3, cap_tiles, st);
-            case 4: return launch_kv_rows<4>(k, x3, cap_tiles, st);
-            case 6: return launch_kv_rows<6>(k, x3, cap_tiles, st);
-            case 8: return launch_kv_rows<8>(k, x3, cap_tiles, st);
+            case 2: return launch_kv_rows<2>(k, x3, t_f16 != 0, cap_tiles, st);
+            case 4: return launch_kv_rows<4>(k, x3, t_f16 != 0, cap_tiles, st);
+            case 6: return launch_kv_rows<6>(k, x3, t_f16 != 0, cap_tiles, st);
+            case 8: return launch_kv_rows<8>(k, x3, t_f16 != 0, cap_tiles, st);
             default: return LVQ_EUNSUPPORTED;
         }
     }

@@ -275,6 +275,9 @@ def bev_tile_kv(feat: torch.Tensor, idx: torch.Tensor, live: torch.Tensor, dirty
     n2 = m[0].shape[0]
     if out.dtype != torch.bfloat16 or not out.is_contiguous() or out.shape[0] < cap_rows or out.shape[1] != n2 or t_tiled.shape[1] != n2:
         raise F.LvqError("bev_tile_kv: `out` must be a contiguous bf16 [>= cap_rows, 2n] buffer and the table [HW, 2n]")
+    t_f16 = t_tiled.dtype == torch.float16                       # fp16 table: two-launch form only
+    if t_tiled.dtype not in (torch.float16, torch.float32) or (t_f16 and not split_launch):
+        raise F.LvqError("bev_tile_kv: the table is fp32, or fp16 with the two-launch form")
     L = F.lib()
     cap_tiles = batch * (ny // 8) * (nx // 8)
     ws = None
@@ -288,7 +291,8 @@ def bev_tile_kv(feat: torch.Tensor, idx: torch.Tensor, live: torch.Tensor, dirty
     with region(tag, feat.device):
         rc = L.lvq_bev_tile_kv(F.ptr(feat), F.ptr(idx), F.ptr(live), F.ptr(dirty), F.ptr(counts), F.i64(cap_tiles), F.cint(batch),
                                F.cint(ny), F.cint(nx), F.cint(feat.shape[1]), F.ptr(w9), F.ptr(b9), F.ptr(m[0]), F.ptr(m[1]), F.ptr(m0), F.ptr(r[0]),
-                               F.ptr(r[1]), F.ptr(r0), F.cfloat(c0), F.cint(d_ln), F.cfloat(eps), F.ptr(t_tiled), F.cint(n2 // 2), F.cint(1 if k_fp16 else 0), F.ptr(out),
+                               F.ptr(r[1]), F.ptr(r0), F.cfloat(c0), F.cint(d_ln), F.cfloat(eps), F.ptr(t_tiled), F.cint(1 if t_f16 else 0), F.cint(n2 // 2),
+                               F.cint(1 if k_fp16 else 0), F.ptr(out),
                                F.ptr(ws), F.csize(ws.numel() if ws is not None else 0), F.stream_ptr(feat.device))
     F.check(rc, "lvq_bev_tile_kv")
     return out

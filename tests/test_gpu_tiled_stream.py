@@ -344,27 +344,36 @@ def test_fused_kv_kernel_matches_token_kernel_plus_gemm(prec, monkeypatch):
     """lvq_bev_tile_kv (LayerNorm and the K|V projection folded onto the 64-channel conv token: K|V = rstd (M t + m0) + T[key]) against
     the unfused pair lvq_bev_tile_tokens -> lvq_gemm_bf16_live_rows on the same scenes: the K|V rows of the dirty cells and of the
     per-model table agree to the rounding of the bf16 result (the fused form skips the bf16 rounding of the d-wide token), and so do
-    the LiDAR tokens."""
+    the LiDAR tokens.  The two-launch form equals the single-kernel form bit for bit (same arithmetic), and the fp16 table (default)
+    moves a row by at most one bf16 ulp against the fp32 table."""
     cfg = tiled_cfg()
     pipe = P.FusionPipeline(cfg, DEV, precision=prec)
     pts, off, patches, _, _ = P.synthetic_batch(cfg, 2, 1001, DEV)
     h, w = cfg.bev_hw
-    a = pipe(pts, off, patches)
     vl = pipe.vat_lidar
-    kv_f = [b.clone() for b in vl._pe_cache[("kv_buffer", h, w, torch.device(DEV))][1]]
+    key = ("kv_buffer", h, w, torch.device(DEV))
+    a16 = pipe(pts, off, patches)                                 # default: two launches, fp16 table
+    kv16 = [b.clone() for b in vl._pe_cache[key][1]]
     nd = int(vl._last_tile_counts[2])
-    # the single-kernel form (k_tile_kv) and the default two-launch form (k_conv_rows + k_kv_rows) do the same arithmetic
+    assert 0 < nd < 2 * h * w
+    monkeypatch.setenv("LVQ_KV_T_FP32", "1")
+    a = pipe(pts, off, patches)                                   # two launches, fp32 table
+    kv_f = [b.clone() for b in vl._pe_cache[key][1]]
+    for x16, x32 in zip(kv16, kv_f):
+        f16, f32 = x16[:h * w + nd].float(), x32[:h * w + nd].float()
+        assert float((f16 - f32).abs().max()) <= 2.0 ** -7 * float(f32.abs().max())                   # one ulp of the largest row entry
+        assert float((f16 != f32).float().mean()) < 0.2                                               # most entries do not move at all
+    assert float((a16["lidar_tokens"] - a["lidar_tokens"]).abs().max()) < (5e-2 if prec == "bf16" else 2e-4)
     monkeypatch.setenv("LVQ_KV_ONE_LAUNCH", "1")
-    vl._pe_cache.pop(("kv_buffer", h, w, torch.device(DEV)))
-    a1 = pipe(pts, off, patches)
-    for f, o1 in zip(kv_f, vl._pe_cache[("kv_buffer", h, w, torch.device(DEV))][1]):
+    a1 = pipe(pts, off, patches)                                  # single kernel, fp32 table: the same arithmetic
+    for f, o1 in zip(kv_f, vl._pe_cache[key][1]):
         assert torch.equal(f[:h * w + nd], o1[:h * w + nd])
     assert torch.equal(a["lidar_tokens"], a1["lidar_tokens"])
     monkeypatch.delenv("LVQ_KV_ONE_LAUNCH")
     monkeypatch.setenv("LVQ_NO_FUSED_KV", "1")
     b = pipe(pts, off, patches)
-    kv_u = vl._pe_cache[("kv_buffer", h, w, torch.device(DEV))][1]
-    assert int(vl._last_tile_counts[2]) == nd and 0 < nd < 2 * h * w
+    kv_u = vl._pe_cache[key][1]
+    assert int(vl._last_tile_counts[2]) == nd
     for f, u in zip(kv_f, kv_u):
         f32, u32 = f[:h * w + nd].float(), u[:h * w + nd].float()
         scale = float(u32.abs().max())
