@@ -353,7 +353,7 @@ class VATLiDAR(_HipModule):
                   self.geo_mlp[2].weight, self.geo_mlp[2].bias, self.view_embed]
         for blk in self.blocks:
             params += [blk.ca.in_proj_weight, blk.ca.in_proj_bias]
-        t16 = not os.environ.get("LVQ_KV_ONE_LAUNCH") and not os.environ.get("LVQ_KV_T_FP32")      # fp16 table: two-launch form only
+        t16 = bool(os.environ.get("LVQ_KV_T_FP16")) and not os.environ.get("LVQ_KV_ONE_LAUNCH")    # opt-in fp16 table (two-launch form only)
         ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(), t16)
         key = ("kv_fold", H, W, dev)
         hit = self._pe_cache.get(key)
@@ -384,6 +384,9 @@ class VATLiDAR(_HipModule):
             t_tab, _ = ops.linear(a_pe, blk._w(blk.ca.in_proj_weight), blk.ca.in_proj_bias, out_f32=True, w_rows=(d, 3 * d))
             # the table as fp16 when its values fit (checked once, here): its 2^-12 rounding disappears under the bf16 rounding of the
             # rows, and the kernel's largest read stream halves (two-launch form only; dtype conversion = plumbing)
+            # LVQ_KV_T_FP16=1: the table as IEEE fp16 (values checked here) -- half the bytes of k_kv_rows' largest read stream, 4.5 -> 3.8 ms,
+            # +4 % tokens/s.  Opt-in, because it is not free: rounding T to 11 bits moves the fused tokens by 1.4e-4 (1.04e-4 -> 2.4e-4 against
+            # the oracle; linear in the rounding -- bf16 would cost 1.5e-3 -- and mostly through the V half: DESIGN 3.3)
             if t16 and float(t_tab.abs().max()) < 3.0e4:
                 t_tab = t_tab.to(torch.float16)
             layers.append((m_bf, m0, t_tab))
@@ -409,7 +412,7 @@ class VATLiDAR(_HipModule):
             params += [blk.ca.in_proj_weight, blk.ca.in_proj_bias]
         fused = not os.environ.get("LVQ_NO_FUSED_KV")
         ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(), fused, k16, bool(os.environ.get("LVQ_KV_ONE_LAUNCH")),
-                                                                   bool(os.environ.get("LVQ_KV_T_FP32")))
+                                                                   bool(os.environ.get("LVQ_KV_T_FP16")))
         key = ("kv_buffer", H, W, dev)
         hw, d = H * W, self.d_model
         rows = hw + batch * hw

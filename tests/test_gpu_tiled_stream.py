@@ -344,20 +344,21 @@ def test_fused_kv_kernel_matches_token_kernel_plus_gemm(prec, monkeypatch):
     """lvq_bev_tile_kv (LayerNorm and the K|V projection folded onto the 64-channel conv token: K|V = rstd (M t + m0) + T[key]) against
     the unfused pair lvq_bev_tile_tokens -> lvq_gemm_bf16_live_rows on the same scenes: the K|V rows of the dirty cells and of the
     per-model table agree to the rounding of the bf16 result (the fused form skips the bf16 rounding of the d-wide token), and so do
-    the LiDAR tokens.  The two-launch form equals the single-kernel form bit for bit (same arithmetic), and the fp16 table (default)
-    moves a row by at most one bf16 ulp against the fp32 table."""
+    the LiDAR tokens.  The two-launch form equals the single-kernel form bit for bit (same arithmetic), and the fp16 table
+    option (LVQ_KV_T_FP16) moves a row by at most one bf16 ulp against the fp32 table."""
     cfg = tiled_cfg()
     pipe = P.FusionPipeline(cfg, DEV, precision=prec)
     pts, off, patches, _, _ = P.synthetic_batch(cfg, 2, 1001, DEV)
     h, w = cfg.bev_hw
     vl = pipe.vat_lidar
     key = ("kv_buffer", h, w, torch.device(DEV))
-    a16 = pipe(pts, off, patches)                                 # default: two launches, fp16 table
+    monkeypatch.setenv("LVQ_KV_T_FP16", "1")
+    a16 = pipe(pts, off, patches)                                 # two launches, fp16 table (opt-in)
     kv16 = [b.clone() for b in vl._pe_cache[key][1]]
     nd = int(vl._last_tile_counts[2])
     assert 0 < nd < 2 * h * w
-    monkeypatch.setenv("LVQ_KV_T_FP32", "1")
-    a = pipe(pts, off, patches)                                   # two launches, fp32 table
+    monkeypatch.delenv("LVQ_KV_T_FP16")
+    a = pipe(pts, off, patches)                                   # default: two launches, fp32 table
     kv_f = [b.clone() for b in vl._pe_cache[key][1]]
     for x16, x32 in zip(kv16, kv_f):
         f16, f32 = x16[:h * w + nd].float(), x32[:h * w + nd].float()
