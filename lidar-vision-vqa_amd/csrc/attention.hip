@@ -541,6 +541,25 @@ __device__ __forceinline__ void lds_tr_wait4(bf16x4 &a, bf16x4 &b, bf16x4 &c, bf
     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
 }
 
+// fragment reads of the pipelined stream (k_attn32<..., PIPE>): four K fragments (ds_read_b128) / the eight transposed V fragments of
+// one 32-key block, as asm for the same reason; waited for by lds_wait_k / lds_wait_v
+template <int OFF>
+__device__ __forceinline__ void lds_k_read4(bf16x8 (&kf)[4], uint32_t sb, const uint32_t (&kl)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[ks]) : "v"(sb + kl[ks]), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_v_read8(bf16x4 (&va)[8], uint32_t e0, uint32_t e1, uint32_t o0, uint32_t o1) {
+    va[0] = lds_tr_read_o<OFF>(e0);        va[1] = lds_tr_read_o<OFF + 1024>(o0);  va[2] = lds_tr_read_o<OFF>(e1);        va[3] = lds_tr_read_o<OFF + 1024>(o1);
+    va[4] = lds_tr_read_o<OFF + 2048>(e0); va[5] = lds_tr_read_o<OFF + 3072>(o0);  va[6] = lds_tr_read_o<OFF + 2048>(e1); va[7] = lds_tr_read_o<OFF + 3072>(o1);
+}
+__device__ __forceinline__ void lds_wait_k(bf16x8 (&kf)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3])::"memory");
+}
+__device__ __forceinline__ void lds_wait_v(bf16x4 (&va)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(va[4]), "+v"(va[5]), "+v"(va[6]), "+v"(va[7])::"memory");
+}
+
 // QS = 1 ("mixed" precision): Q arrives as hi + lo and every score is K . (Q_hi + Q_lo) -- two MFMAs per K fragment on
 // the same accumulator -- while K, V and P stay plain bf16.  Rounding Q is the same perturbation for every key of a row, so it
 // does not average out over the stream the way the per-key roundings of K, V and P do (tools/precision_study.py: 2.8e-3 of the
@@ -548,11 +567,16 @@ __device__ __forceinline__ void lds_tr_wait4(bf16x4 &a, bf16x4 &b, bf16x4 &c, bf
 // QS = 2 ("mixed16"): Q as ONE fp16 operand (hi + lo summed, scaled, rounded to 11 bits) against K stored as fp16 -- one MFMA per K
 // fragment at the bf16 rate; P and V stay bf16.  Q's rounding is common to all keys of a row, so the result carries ~3.5x the error of
 // QS = 1 (3.7e-4 instead of 1.1e-4 on the bench scene), for 2/3 of its MFMA passes.
-template <int NW, int QS, int TL = 0>
-__global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
+// PIPE: the fast stream as ONE software-pipelined instruction stream per wave (stream_pipe below): the score MFMAs of the next 32-key
+// block are issued between the exponentials of the current one, so a wave overlaps its own matrix and vector work instead of relying
+// on the other waves of its SIMD to do so; 4 LDS slots, 2 waves per SIMD (256 registers).
+template <int NW, int QS, int TL = 0, bool PIPE = false>
+__global__ void __launch_bounds__(NW * 64, PIPE ? 2 : 3) k_attn32(AttnArgs a) {
     constexpr int DH = 64, KROW = 64, CH = 8, NT = NW * 64;
     constexpr int NLD = (KVB * CH + NT - 1) / NT;
     constexpr int TILE_E = 2 * KVB * KROW;                     // K + V of one stage (bf16 elements)
+    constexpr int NSLOT = PIPE ? 4 : 3;                        // LDS slots of the K|V ring
+    static_assert(!PIPE || NW == 4, "the pipelined stream is written for 4 waves (4 DMA pieces per wave and tile)");
     constexpr float THR = 6.0f;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem[];
     // wid through readfirstlane: the compiler does not know tid >> 6 is wave-uniform, and everything derived from it (which DMA
@@ -653,7 +677,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     // tile's requests went out; the address is one v_mad_u64_u32 per piece on top of the piece's scalar base.
     constexpr int WIN_T = 8, WIN_W = WIN_T * KVB;              // tiles / words per window
     const int32_t *tsrc_b = !tiled ? nullptr : pair_mode ? a.pair_src + (int64_t)wave_b * a.pair_cap * KVB : a.row_src + (int64_t)wave_b * (a.Nkv / KVB) * KVB;
-    int32_t *win = reinterpret_cast<int32_t *>(smem + 3 * TILE_E) + 4;          // [2][512] behind the ring and the redo flag
+    int32_t *win = reinterpret_cast<int32_t *>(smem + NSLOT * TILE_E) + 4;      // [2][512] behind the ring and the redo flag
     auto win_dma = [&](int w) __attribute__((always_inline)) {                   // wave 0: window w = tiles t0 + 8 w .. + 7
         const int n_e = n_tiles * KVB;
 #pragma unroll
@@ -836,6 +860,174 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
         }
     };
 
+    // ---- PIPE: the pipelined fast stream -------------------------------------------------------------------------------------
+    // One tile = block A (keys 0..31) and block B (keys 32..63).  Per iteration t, with S_A(t) already in sc0:
+    //   P1  S_B(t) -> sc1 (8 MFMAs; 4 without the Q split), between them exp / pack of sc0          [V_A(t) fragments requested]
+    //   B1  tile t+1 has landed (counted vmcnt, barrier); tile t+3 requested into the slot of t-1;   [K_A(t+1) fragments requested]
+    //   P2  O += V_A P_A (4 MFMAs), between them the row-sum chain of block A
+    //   P3  S_A(t+1) -> sc0, between them exp / pack of sc1                                           [V_B(t) fragments requested]
+    //   P4  O += V_B P_B, row-sum chain of block B                                                    [K_B(t+1) fragments requested]
+    // Every MFMA is followed by at most ~24 cycles of vector issue (MI355X: an MFMA holds the issue port for 8 of its 32 cycles) and a
+    // sched_barrier pins that placement.  All LDS fragment reads are asm (invisible to the compiler's waitcnt pass, see lds_tr_read)
+    // and are waited for with lgkmcnt(0) one phase (>= 128 cycles) after their issue.  Arithmetic and summation order are those of
+    // tile_fast: the two forms are bit-identical.
+    [[maybe_unused]] auto stream_pipe = [&]() __attribute__((always_inline)) {
+        if (!(t0 < t1)) return;
+        constexpr int NM = (QS == 1 || QS == 3) ? 8 : 4;           // score MFMAs per 32-key block
+        constexpr int GPM = 8 / NM;                                // exp groups (2 scores each) per MFMA gap
+        const uint32_t sbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint16_t *)smem);
+        uint32_t kl[4];                                            // K fragment byte offsets inside a slot (block A; block B: + 4096)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) kl[ks] = (uint32_t)(2 * (l31 * KROW + (((2 * ks + hi) ^ fk) << 3)));
+        bf16x8 kf[4];
+        bf16x4 va[8];
+        auto k_reads = [&](uint32_t sb, auto kb_tag) __attribute__((always_inline)) { lds_k_read4<decltype(kb_tag)::value * 4096>(kf, sb, kl); };
+        auto v_reads = [&](uint32_t sb, auto kb_tag) __attribute__((always_inline)) {
+            lds_v_read8<2 * KVB * KROW + decltype(kb_tag)::value * 4096>(va, sb + vlane[0][0], sb + vlane[0][1], sb + vlane[1][0], sb + vlane[1][1]);
+        };
+        auto wait_k = [&]() __attribute__((always_inline)) { lds_wait_k(kf); };
+        auto wait_v = [&]() __attribute__((always_inline)) { lds_wait_v(va); };
+        auto s_mfma = [&](f32x16 &sc, int m) __attribute__((always_inline)) {     // m-th score MFMA of a block (m compile-time after unrolling)
+            const int ks = NM == 8 ? (m >> 1) : m;
+            const bool lo = NM == 8 && (m & 1);
+            if (QS >= 2) sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf[ks]), __builtin_bit_cast(f16x8, lo ? qfl[QS == 3 ? ks : 0] : qf[ks]), sc, 0, 0, 0);
+            else         sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], lo ? qfl[QS == 1 ? ks : 0] : qf[ks], sc, 0, 0, 0);
+        };
+        uint32_t pk[8];
+        float tg[8], xa[2], xb[2];
+        // exp of the two scores of group g of a finished block (soft_e), their pair sum and packed bf16 pair one gap later (soft_f: a
+        // transcendental's result costs a wait state when the very next vector instruction reads it).  neg: the pair goes into a
+        // SUBTRACTED block -- source modifiers of the conversion, no extra instruction
+        auto soft_e = [&](const f32x16 &sc, int g) __attribute__((always_inline)) {
+            xa[g & 1] = fast_exp2(sc[2 * g]);
+            xb[g & 1] = fast_exp2(sc[2 * g + 1]);
+            asm volatile("" : "+v"(xa[g & 1]), "+v"(xb[g & 1]));   // computed HERE (see soft_f)
+        };
+        auto soft_f = [&](int g, auto neg_tag) __attribute__((always_inline)) {
+            const float x0 = xa[g & 1], x1 = xb[g & 1];
+            tg[g] = x0 + x1;
+            pk[g] = decltype(neg_tag)::value ? pack_bf16(-x0, -x1) : pack_bf16(x0, x1);
+            asm volatile("" : "+v"(tg[g]), "+v"(pk[g]));           // computed HERE: the IR sinks unpinned values past B1 to their first use
+        };
+        // O += V P of one block with the row-sum chain in the gaps (the last group's soft_f first)
+        auto pv = [&](auto neg_tag) __attribute__((always_inline)) {
+            constexpr bool NEG = decltype(neg_tag)::value;
+            soft_f(7, neg_tag);
+            uint4 u0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), u1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            const bf16x8 pf0 = *reinterpret_cast<bf16x8 *>(&u0), pf1 = *reinterpret_cast<bf16x8 *>(&u1);
+            float ls = 0.f;
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(va[0], va[1], 0, 1, 2, 3, 4, 5, 6, 7), pf0, o[0], 0, 0, 0);
+            ls += tg[0]; ls += tg[1];
+            __builtin_amdgcn_sched_barrier(0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(va[2], va[3], 0, 1, 2, 3, 4, 5, 6, 7), pf0, o[1], 0, 0, 0);
+            ls += tg[2]; ls += tg[3];
+            __builtin_amdgcn_sched_barrier(0);
+            o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(va[4], va[5], 0, 1, 2, 3, 4, 5, 6, 7), pf1, o[0], 0, 0, 0);
+            ls += tg[4]; ls += tg[5];
+            __builtin_amdgcn_sched_barrier(0);
+            o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(va[6], va[7], 0, 1, 2, 3, 4, 5, 6, 7), pf1, o[1], 0, 0, 0);
+            ls += tg[6]; ls += tg[7];
+            lsum = NEG ? lsum - ls : lsum + ls;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 sc0, sc1;
+
+        // ---- prologue: window, tiles t0 .. t0+2 requested, S_A(t0)
+        if (tiled) {
+            if (wid == 0) win_dma(0);                              // window 1 follows at tile t0 + 4
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            win_read(t0);
+        }
+        dma(t0, 0);
+        if (t0 + 1 < t1) dma(t0 + 1, 1);
+        if (t0 + 2 < t1) dma(t0 + 2, 2);
+        if (t0 + 2 < t1)      __builtin_amdgcn_s_waitcnt(8 | 0x70);         // tile t0 landed, two requests (4 pieces each) may fly
+        else if (t0 + 1 < t1) __builtin_amdgcn_s_waitcnt(4 | 0x70);
+        else                  __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_s_barrier();
+        if (q0 >= a.Nq) {
+            // a wave without queries (the padding of the last query tile: 2 of 20 waves at 576 queries) only keeps its share of the
+            // K|V stream moving: the same waits, barriers and requests as the loop below, no matrix or vector work
+            for (int t = t0; t + 1 < t1; ++t) {
+                if (t + 2 < t1) __builtin_amdgcn_s_waitcnt(4 | 0x70);
+                else            __builtin_amdgcn_s_waitcnt(0x0070);
+                __builtin_amdgcn_s_barrier();
+                if (t + 3 < t1) dma(t + 3, (t - t0 + 3) & 3);
+            }
+            return;
+        }
+        k_reads(sbase, std::integral_constant<int, 0>{});
+        wait_k();
+        sc0 = zero16;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) s_mfma(sc0, m);
+        k_reads(sbase, std::integral_constant<int, 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+
+        auto body = [&](int t, auto more_tag, auto neg_tag) __attribute__((always_inline)) {
+            constexpr bool MORE = decltype(more_tag)::value;       // a tile t+1 exists
+            const int sl = (t - t0) & 3;
+            const uint32_t sb = sbase + (uint32_t)sl * (uint32_t)(TILE_E * 2);
+            const uint32_t sb1 = sbase + (uint32_t)((sl + 1) & 3) * (uint32_t)(TILE_E * 2);
+            // P1
+            wait_k();                                              // K_B(t)
+            v_reads(sb, std::integral_constant<int, 0>{});         // V_A(t)
+            sc1 = zero16;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                s_mfma(sc1, m);
+#pragma unroll
+                for (int gg = 0; gg < GPM; ++gg) {
+                    const int g = m * GPM + gg;
+                    soft_e(sc0, g);
+                    if (g > 0) soft_f(g - 1, std::false_type{});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wait_v();
+            if (MORE) {
+                // B1
+                if (t + 2 < t1) __builtin_amdgcn_s_waitcnt(4 | 0x70);        // tile t+1 landed, the request for t+2 may fly
+                else            __builtin_amdgcn_s_waitcnt(0x0070);
+                __builtin_amdgcn_s_barrier();
+                if (t + 3 < t1) dma(t + 3, (sl + 3) & 3);
+                k_reads(sb1, std::integral_constant<int, 0>{});    // K_A(t+1)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // P2
+            pv(std::false_type{});
+            // P3
+            if (MORE) wait_k();
+            v_reads(sb, std::integral_constant<int, 1>{});         // V_B(t)
+            if (MORE) sc0 = zero16;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                if (MORE) s_mfma(sc0, m);
+#pragma unroll
+                for (int gg = 0; gg < GPM; ++gg) {
+                    const int g = m * GPM + gg;
+                    soft_e(sc1, g);
+                    if (g > 0) soft_f(g - 1, neg_tag);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            wait_v();
+            if (MORE) k_reads(sb1, std::integral_constant<int, 1>{});   // K_B(t+1)
+            // P4
+            pv(neg_tag);
+        };
+        int t = t0;
+        if (TL == 2 && pair_mode) {                                // keys 32..63 of every tile are subtracted
+            for (; t + 1 < t1; ++t) body(t, std::true_type{}, std::true_type{});
+            body(t, std::false_type{}, std::true_type{});
+        } else {
+            for (; t + 1 < t1; ++t) body(t, std::true_type{}, std::false_type{});
+            body(t, std::false_type{}, std::false_type{});
+        }
+    };
+
     // DMA bookkeeping shared by the three loop forms below
     int slot = 0;
     auto pre = [&](int t) __attribute__((always_inline)) {
@@ -861,9 +1053,10 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     // loop therefore has no row maximum, no branch, no rescale and no accumulator initialisation: a rescale inside it, even behind
     // a never-taken branch, made the compiler copy the 32 accumulator registers every tile, and the 17-step v_max3 chain sat
     // between the score MFMAs and the first exp.
-    uint32_t *redo_flag = reinterpret_cast<uint32_t *>(smem + 3 * TILE_E);
+    uint32_t *redo_flag = reinterpret_cast<uint32_t *>(smem + NSLOT * TILE_E);
     auto stream = [&](auto slow_tag) __attribute__((always_inline)) {
         constexpr bool SLOW = decltype(slow_tag)::value;
+        if constexpr (PIPE && !SLOW) { stream_pipe(); return; }
         slot = 0;
         if (tiled && t0 < t1) {                                // (an empty range reads nothing: a pair list may have no tiles at all)
             if (wid == 0) win_dma(0);                          // window 1 follows at tile t0 + 4
@@ -927,7 +1120,7 @@ __global__ void __launch_bounds__(NW * 64, 3) k_attn32(AttnArgs a) {
     if (tid == 0) *redo_flag = 0;
     stream(std::false_type{});
     fresh = !(t0 < t1);
-    if (t0 < t1 && !pair_mode) {                                // a signed partial may be anything; the combine kernel judges the total
+    if (t0 < t1 && !pair_mode && !(PIPE && q0 >= a.Nq)) {       // a signed partial may be anything; the combine kernel judges the total
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lsum), __float_as_uint(lsum), false, false);
         const float ltot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         if (!(ltot < 1.2676506e30f) || !(ltot > 7.8886091e-31f)) *redo_flag = 1;      // outside [2^-100, 2^100]; also catches inf / NaN
@@ -1293,7 +1486,18 @@ extern "C" size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, 
 extern "C" int lvq_attention_stream_ok(int nq, int nkv, int dh) { return plan_k32_waves(nq, nkv, dh, false) != 0; }
 
 namespace {
+template <int QS, int TL> void launch_k32_pipe(const AttnArgs &a, int64_t nwg, size_t lds, hipStream_t st) {
+    const size_t l = lds + (size_t)2 * KVB * 64 * sizeof(uint16_t);                         // a fourth K+V slot
+    hipFuncSetAttribute((const void *)k_attn32<4, QS, TL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
+    hipLaunchKernelGGL((k_attn32<4, QS, TL, true>), dim3((unsigned)nwg), dim3(256), l, st, a);
+}
 template <int TL> void launch_k32(const AttnArgs &a, int nw, int qs, int64_t nwg, size_t lds, hipStream_t st) {
+    if (nw == 4 && getenv("LVQ_ATTN_PIPE") != nullptr) {
+        if (qs == 2)  launch_k32_pipe<2, TL>(a, nwg, lds, st);
+        else if (qs)  launch_k32_pipe<1, TL>(a, nwg, lds, st);
+        else          launch_k32_pipe<0, TL>(a, nwg, lds, st);
+        return;
+    }
     if (qs == 2) {
         if (nw == 6) hipLaunchKernelGGL((k_attn32<6, 2, TL>), dim3((unsigned)nwg), dim3(384), lds, st, a);
         else         hipLaunchKernelGGL((k_attn32<4, 2, TL>), dim3((unsigned)nwg), dim3(256), lds, st, a);
