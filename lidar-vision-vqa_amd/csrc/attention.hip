@@ -1303,7 +1303,14 @@ int plan_k32_waves(int nq, int nkv, int dh, bool split) {      // split = K / V 
     }
     return 0;
 }
-AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, bool allow32 = false) {
+// the pipelined form of k_attn32 (2 workgroups per CU) is opt-in (LVQ_ATTN_PIPE=1): bit-identical to the default form and 0-7 % faster on
+// the split-query streams (+0.5 % on the bench step), 2-5 % slower with a plain query (4 score MFMAs per block for the same 16
+// exponentials); DESIGN 3.2 has the measurements and what they say about the stream's bound.  A/B: tools/ab_attn_pipe.py
+bool k32_pipe(int nw, int qs) {
+    (void)qs;
+    return nw == 4 && getenv("LVQ_ATTN_PIPE") != nullptr;
+}
+AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, bool allow32 = false, int qs = 0) {
     AttnPlan p;
     p.k32 = allow32 ? plan_k32_waves(nq, nkv, dh, split) : 0;
     if (p.k32) {
@@ -1318,13 +1325,14 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, 
         {
             // dispatch-round quantisation: 3 (4-wave) or 2 (6-wave) workgroups fit per CU; among the split counts near the
             // target pick the one whose last round is fullest (576 queries, 4 scenes: 18 splits = 5.6 rounds, 16 = 5.0)
-            const int64_t slots = (int64_t)256 * (p.k32 == 4 ? 3 : 2);
+            const int64_t slots = (int64_t)256 * (p.k32 == 4 && !k32_pipe(p.k32, qs) ? 3 : 2);
             double best = 1e30;
             int best_ns = ns;
-            for (int c = ns > 4 ? ns - 4 : 1; c <= ns + 1 && c <= 64 && c <= (n_tiles / 8 > 0 ? n_tiles / 8 : 1); ++c) {
+            for (int c = ns > 4 ? ns - 4 : 1; c <= ns + 2 && c <= 64 && c <= (n_tiles / 8 > 0 ? n_tiles / 8 : 1); ++c) {
                 const int64_t wgs = base * c;
                 const double waste = (double)((wgs + slots - 1) / slots * slots) / (double)wgs;
-                if (wgs >= 3 * slots && waste < best - 1e-9) { best = waste; best_ns = c; }
+                // (2 workgroups per CU: among equal fills the finer split ran faster -- 8 scenes: 8 splits 5.43 ms, 5 splits 5.96)
+                if (wgs >= 3 * slots && (waste < best - 1e-9 || (slots == 512 && waste < best + 1e-9))) { best = waste; best_ns = c; }
             }
             ns = best_ns;
         }
@@ -1466,11 +1474,19 @@ __global__ void __launch_bounds__(256) k_transpose_bf16(const uint16_t *__restri
 
 }  // namespace
 
+// the long-stream plan with the larger KV split of the two query kinds (workspace queries do not know which one will be launched)
+static AttnPlan plan_k32_any(int batch, int n_heads, int nq, int nkv, int dh) {
+    const AttnPlan a = plan_attn(batch, n_heads, nq, nkv, dh, false, true, 0), b = plan_attn(batch, n_heads, nq, nkv, dh, false, true, 1);
+    return b.nsplit > a.nsplit ? b : a;
+}
+
 extern "C" size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, int nkv, int dh, int precision) {
     if (dh <= 128 && (dh & 15) == 0) {              // fused kernel: workspace only for the KV-split partials
         const AttnPlan p = plan_attn(batch, n_heads, nq, nkv, dh, precision == 3);
         const AttnPlan p32 = plan_attn(batch, n_heads, nq, nkv, dh, precision == 3, true);   // chosen when there is no bias / mask
-        const int ns = p.nsplit > p32.nsplit ? p.nsplit : p32.nsplit;
+        const AttnPlan p32q = plan_attn(batch, n_heads, nq, nkv, dh, precision == 3, true, 1);   // ... and the query is split
+        int ns = p.nsplit > p32.nsplit ? p.nsplit : p32.nsplit;
+        if (p32q.nsplit > ns) ns = p32q.nsplit;
         if (ns == 1) return 256;
         return lvq_align((size_t)batch * n_heads * ns * nq * (dh + 2) * sizeof(float)) + 256;
     }
@@ -1492,7 +1508,7 @@ template <int QS, int TL> void launch_k32_pipe(const AttnArgs &a, int64_t nwg, s
     hipLaunchKernelGGL((k_attn32<4, QS, TL, true>), dim3((unsigned)nwg), dim3(256), l, st, a);
 }
 template <int TL> void launch_k32(const AttnArgs &a, int nw, int qs, int64_t nwg, size_t lds, hipStream_t st) {
-    if (nw == 4 && getenv("LVQ_ATTN_PIPE") != nullptr) {
+    if (k32_pipe(nw, qs)) {
         if (qs == 2)  launch_k32_pipe<2, TL>(a, nwg, lds, st);
         else if (qs)  launch_k32_pipe<1, TL>(a, nwg, lds, st);
         else          launch_k32_pipe<0, TL>(a, nwg, lds, st);
@@ -1537,7 +1553,8 @@ extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo,
     a.v_bs = 0; a.ldv = ldkv; a.v_hs = kv_hstride; a.o_bs = o_bstride; a.ldo = ldo; a.o_hs = o_hstride;
     a.scale = scale; a.causal = 0; a.o = o; a.ol = o_lo;
     a.row_src = row_src;
-    const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, false, true);
+    const int qs = k_fp16 ? 2 : (q_lo != nullptr ? 1 : 0);
+    const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, false, true, qs);
     if (!pl.k32) return LVQ_EUNSUPPORTED;
     a.nsplit = pl.nsplit; a.nqt = pl.nqt; a.part = nullptr;
     if (pl.nsplit > 1) {
@@ -1549,7 +1566,7 @@ extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo,
     const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
     const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;
     if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
-    launch_k32<1>(a, pl.k32, k_fp16 ? 2 : (q_lo != nullptr ? 1 : 0), nwg, K32_LDS_TILED, st);
+    launch_k32<1>(a, pl.k32, qs, nwg, K32_LDS_TILED, st);
     if (a.nsplit > 1) {
         const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
         hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
@@ -1569,7 +1586,7 @@ extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo,
 
 // totals [n_heads, nq, dh + 2] fp32 (unnormalised O | m | l) of ONE batch of queries over a dense key stream (the table).
 extern "C" size_t lvq_attention_stream_totals_workspace_bytes(int n_heads, int nq, int nkv, int dh) {
-    const AttnPlan pl = plan_attn(1, n_heads, nq, nkv, dh, false, true);
+    const AttnPlan pl = plan_k32_any(1, n_heads, nq, nkv, dh);
     if (!pl.k32) return 0;
     return (size_t)n_heads * pl.nsplit * nq * (dh + 2) * sizeof(float) + 256;
 }
@@ -1580,7 +1597,8 @@ extern "C" int lvq_attention_bf16_stream_totals(const lvq_bf16 *q, const lvq_bf1
     if (dh != 64 || (ldq & 7) || (ldkv & 7) || (q_hstride & 7) || (kv_hstride & 7) || n_heads > 65535) return LVQ_EUNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)q_lo | (uintptr_t)k | (uintptr_t)v | (uintptr_t)totals) & 15) return LVQ_EUNSUPPORTED;
     if (((int64_t)nkv * ldkv + dh) * 2 >= (1ll << 32)) return LVQ_EUNSUPPORTED;
-    const AttnPlan pl = plan_attn(1, n_heads, nq, nkv, dh, false, true);
+    const int qs = k_fp16 == 2 ? 0 : k_fp16 ? 2 : (q_lo != nullptr ? 1 : 0);            // (the fp16 hi + lo form has no pipelined variant)
+    const AttnPlan pl = plan_attn(1, n_heads, nq, nkv, dh, false, true, qs);
     if (!pl.k32) return LVQ_EUNSUPPORTED;
     AttnArgs a{};
     a.q = q; a.ql = q_lo; a.k = k; a.v = v;
@@ -1598,7 +1616,7 @@ extern "C" int lvq_attention_bf16_stream_totals(const lvq_bf16 *q, const lvq_bf1
         if (pl.k32 == 6) hipLaunchKernelGGL((k_attn32<6, 3, 0>), dim3((unsigned)nwg), dim3(384), lds, st, a);
         else             hipLaunchKernelGGL((k_attn32<4, 3, 0>), dim3((unsigned)nwg), dim3(256), lds, st, a);
     } else {
-        launch_k32<0>(a, pl.k32, k_fp16 ? 2 : (q_lo != nullptr ? 1 : 0), (ngrp + 7) / 8 * 8 * a.nqt, lds, st);
+        launch_k32<0>(a, pl.k32, qs, (ngrp + 7) / 8 * 8 * a.nqt, lds, st);
     }
     const int64_t total = (int64_t)a.H * a.Nq * (a.dh / 4);
     hipLaunchKernelGGL(k_attn_combine_raw, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a, totals);
@@ -1608,7 +1626,7 @@ extern "C" int lvq_attention_bf16_stream_totals(const lvq_bf16 *q, const lvq_bf1
 extern "C" size_t lvq_attention_tiled_signed_workspace_bytes(int batch, int n_heads, int nq, int n_tiles, int dh) {
     const int64_t nkv = (int64_t)n_tiles * KVB;
     if (nkv > 0x7fffffff) return 0;
-    const AttnPlan pl = plan_attn(batch, n_heads, nq, (int)nkv, dh, false, true);
+    const AttnPlan pl = plan_k32_any(batch, n_heads, nq, (int)nkv, dh);
     if (!pl.k32) return 0;
     return (size_t)batch * n_heads * pl.nsplit * nq * (dh + 2) * sizeof(float) + (size_t)batch * n_heads * sizeof(int32_t) + 512;
 }
@@ -1635,7 +1653,8 @@ extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16
         return LVQ_EUNSUPPORTED;
     if (((uintptr_t)o | (uintptr_t)o_lo) & 7) return LVQ_EUNSUPPORTED;
     if (n_heads > 65535 || batch > 65535) return LVQ_EUNSUPPORTED;
-    const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, false, true);
+    const int qs = k_fp16 ? 2 : (q_lo != nullptr ? 1 : 0);
+    const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, false, true, qs);
     if (!pl.k32) return LVQ_EUNSUPPORTED;
     AttnArgs a{};
     a.q = q; a.ql = q_lo; a.k = k_rows; a.v = v_rows;
@@ -1657,7 +1676,6 @@ extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16
     const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
     if (hipMemsetAsync(flags, 0, (size_t)batch * n_heads * sizeof(int32_t), st) != hipSuccess) return LVQ_ELAUNCH;
     a.flags = flags;
-    const int qs = k_fp16 ? 2 : (q_lo != nullptr ? 1 : 0);
     launch_k32<2>(a, pl.k32, qs, nwg, lds, st);
     hipLaunchKernelGGL(k_attn_combine_signed, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
     // predicated full re-run of the flagged (batch, head) pairs: every workgroup of an unflagged pair returns at once
@@ -1700,7 +1718,7 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
         a.v_bs = v_bstride; a.ldv = ldv; a.v_hs = v_hstride; a.o_bs = o_bstride; a.ldo = ldo; a.o_hs = o_hstride;
         a.scale = scale; a.causal = causal; a.o = o; a.ol = o_lo;
         const int dhp = (dh + 31) / 32 * 32;
-        const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, split, bias == nullptr && !causal && (o_lo == nullptr || qsplit));
+        const AttnPlan pl = plan_attn(batch, n_heads, nq, nkv, dh, split, bias == nullptr && !causal && (o_lo == nullptr || qsplit), qsplit ? 1 : 0);
         if (qsplit && !pl.k32) return LVQ_EUNSUPPORTED;
         a.nsplit = pl.nsplit; a.nqt = pl.nqt; a.part = nullptr;
         if (pl.nsplit > 1) {
@@ -1709,17 +1727,10 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
             if (!arena.ok) return LVQ_EWORKSPACE;
         }
         if (pl.k32) {
-            const size_t lds = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16;  // three K+V slots + the redo flag
             const int64_t ngrp = (int64_t)a.B * a.H * a.nsplit;
             const int64_t nwg = (ngrp + 7) / 8 * 8 * a.nqt;       // groups padded to the 8 XCDs (see the kernel's id mapping)
             if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
-            if (qsplit) {
-                if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 1>), dim3((unsigned)nwg), dim3(384), lds, st, a);
-                else              hipLaunchKernelGGL((k_attn32<4, 1>), dim3((unsigned)nwg), dim3(256), lds, st, a);
-            } else {
-                if (pl.k32 == 6)  hipLaunchKernelGGL((k_attn32<6, 0>), dim3((unsigned)nwg), dim3(384), lds, st, a);
-                else              hipLaunchKernelGGL((k_attn32<4, 0>), dim3((unsigned)nwg), dim3(256), lds, st, a);
-            }
+            launch_k32<0>(a, pl.k32, qsplit ? 1 : 0, nwg, K32_LDS, st);
             if (a.nsplit > 1) {
                 const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
                 hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);

@@ -302,6 +302,56 @@ def test_attention_tiled_signed_falls_back_when_unusable(kind):
     assert torch.equal(oh, ref[0]) and torch.equal(ol, ref[1])
 
 
+@pytest.mark.parametrize("B,H,nq,n_tiles,fr,qsplit", [(2, 2, 120, 64, 0.35, True), (3, 4, 576, 128, [0.4, 0.9, 0.0], True), (2, 12, 576, 256, [0.2, 0.45], True),
+                                                      (1, 2, 120, 67, 0.3, True), (2, 2, 240, 72, 0.3, False)])
+def test_pipelined_stream_is_bit_identical(B, H, nq, n_tiles, fr, qsplit, monkeypatch):
+    """LVQ_ATTN_PIPE=1 selects the software-pipelined form of the long-stream kernel (4 LDS slots, loader-only waves for the query
+    padding).  Same arithmetic in the same order: with the KV split pinned, the tiled stream, the per-model totals and the signed
+    pair stream (pair lists of any length, full-list batches, 1 .. n tiles per split) equal the default form bit for bit."""
+    o = ops()
+    kv, src, _ = _row_case(B, H, n_tiles, fr, 31)
+    srcd = src.to(DEV).contiguous()
+    hw = n_tiles * 64
+    d = H * 64
+    res = {}
+    for pipe in (False, True):
+        if pipe:
+            monkeypatch.setenv("LVQ_ATTN_PIPE", "1")
+        else:
+            monkeypatch.delenv("LVQ_ATTN_PIPE", raising=False)
+        out = {}
+        for ns in ("1", "3", "8"):
+            if 8 * int(ns) > n_tiles:
+                continue
+            monkeypatch.setenv("LVQ_ATTN_NSPLIT", ns)
+            qb = o.cast(torch.randn(nq, d, generator=torch.Generator().manual_seed(32)).to(DEV), qsplit)
+            qfull = tuple(None if x is None else x.unsqueeze(0).expand(B, nq, d).reshape(B * nq, d).contiguous() for x in qb)
+            out["tiled", ns] = o.attention_tiled(qfull, kv, srcd, batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=64, scale=0.125)
+            if qsplit:
+                pair_src, pair_info = o.bev_scene_pairs(srcd, B, n_tiles, hw)
+                tot = o.attention_stream_totals(qb, kv[:hw], n_heads=H, nq=nq, nkv=hw, dh=64, scale=0.125)
+                out["totals", ns] = (tot,)
+                out["signed", ns] = o.attention_tiled_signed(qb, kv, srcd, pair_src, pair_info, tot, batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=64,
+                                                             scale=0.125, shared_q=True)
+                if ns == "3":                                     # the fp16 Q K^T form (K half of the buffer as IEEE fp16 bit patterns)
+                    kv_h = kv.clone(); kv_h[:, :d] = kv[:, :d].float().half().view(torch.bfloat16)
+                    tot16 = o.attention_stream_totals(qb, kv_h[:hw], n_heads=H, nq=nq, nkv=hw, dh=64, scale=0.125, k_fp16=True)
+                    out["totals16", ns] = (tot16,)
+                    out["signed16", ns] = o.attention_tiled_signed(qb, kv_h, srcd, pair_src, pair_info, tot16, batch=B, n_heads=H, nq=nq, n_tiles=n_tiles,
+                                                                   dh=64, scale=0.125, shared_q=True, k_fp16=True)
+        res[pipe] = out
+    monkeypatch.delenv("LVQ_ATTN_NSPLIT", raising=False)
+    assert res[False].keys() == res[True].keys() and len(res[True]) > 0
+    for k in res[False]:
+        for a, b in zip(res[False][k], res[True][k]):
+            if a is None:
+                assert b is None
+                continue
+            va = a.view(torch.int16) if a.dtype == torch.bfloat16 else a.view(torch.int32)
+            vb = b.view(torch.int16) if b.dtype == torch.bfloat16 else b.view(torch.int32)
+            assert torch.equal(va, vb), k
+
+
 def tiled_cfg(**kw):
     base = dict(n_points=8192, d_model=256, n_heads=4, n_queries=120, n_layers=2, n_patches=196, voxel_pillar=(0.8, 0.8, 8.0), max_pillars=30000)
     base.update(kw)

@@ -16,12 +16,16 @@ def timeit(fn, iters=3):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 def ab(name, fn, flops):
+    """Outputs with the KV split pinned (same partial sums in both forms -> bit-identical), times with each form's own plan."""
     res = {}
     for mode in ("0", "1"):
+        os.environ.pop("LVQ_ATTN_PIPE", None)
         if mode == "1": os.environ["LVQ_ATTN_PIPE"] = "1"
-        else: os.environ.pop("LVQ_ATTN_PIPE", None)
+        os.environ["LVQ_ATTN_NSPLIT"] = "8"
         out = fn(); torch.cuda.synchronize()
-        res[mode] = ([o.clone() for o in out if o is not None] if isinstance(out, (tuple, list)) else [out.clone()], timeit(fn))
+        outs = [o.clone() for o in out if o is not None] if isinstance(out, (tuple, list)) else [out.clone()]
+        os.environ.pop("LVQ_ATTN_NSPLIT")
+        res[mode] = (outs, timeit(fn))
     os.environ.pop("LVQ_ATTN_PIPE", None)
     same = all(torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b)
                for a, b in zip(res["0"][0], res["1"][0]))
