@@ -193,6 +193,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # one rank per GPU.  With fewer devices than ranks (a rehearsal of the N > 1 path on a one-GPU box) the ranks share devices and the
+    # process group falls back to gloo -- RCCL refuses two ranks on one device; such a line says so in config.parallelism
+    ndev = torch.cuda.device_count()
+    rehearsal = world > ndev
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.set_grad_enabled(False)      # inference path (the reference's eval / no_grad mode)
@@ -200,7 +205,7 @@ def main():
     from lidar_vision_vqa_amd import dist as D
     from lidar_vision_vqa_amd import fusion, ops, pipeline as P
 
-    D.init_dist_if_needed()
+    D.init_dist_if_needed("gloo" if rehearsal else None)
     cfg = P.PipelineConfig()
     pipe = P.FusionPipeline(cfg, dev, precision=args.precision)
     S = args.scenes
@@ -320,7 +325,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: " + cfg.describe(), "scenes_per_gpu_per_step": S,
-                   "fused_tokens_per_scene": cfg.n_queries, "parallelism": f"scene-parallel x{world}",
+                   "fused_tokens_per_scene": cfg.n_queries, "parallelism": f"scene-parallel x{world}" + (f" (REHEARSAL: {world} ranks on {ndev} device(s), gloo)" if rehearsal else ""),
                    "precision_mode": args.precision + " (bf16 MFMA tiles throughout; see parity_vs_cpu for the error of every mode)"},
         "roofline": roofline, "roofline_kv_proj": roofline_kv, "roofline_bev_kv": roofline_bev_kv, "roofline_attention": roofline_attn,
     }
