@@ -710,28 +710,35 @@ __global__ void __launch_bounds__(NW * 64, PIPE ? 2 : 3) k_attn32(AttnArgs a) {
         const int pc = wid + NW * j, isv = (pc >> 3) & 1;
         lbj[j] = reinterpret_cast<uint64_t>(isv ? vbase : kbase);
     }
-    auto dma = [&](int t, int slot) __attribute__((always_inline)) {
+    // one DMA piece (j-th of this wave) of tile t into `slot`; dma_head / dma_tail are the window bookkeeping around a tile's pieces
+    auto dma_head = [&](int t) __attribute__((always_inline)) {
         // tiled: refill the other window once every wave is 4 tiles into the current one (nobody reads the old buffer any more)
         if (tiled && wid == 0 && ((t - t0) & (WIN_T - 1)) == 4) win_dma(((t - t0) >> 3) + 1);
-        const uint16_t *kt = tiled ? nullptr : kbase + t * kstep, *vt = tiled ? nullptr : vbase + t * vstep;   // wave-uniform
-#pragma unroll
-        for (int j = 0; j < NPC; ++j) {
-            const int pc = wid + NW * j;                       // wave-uniform
-            if (pc < 16) {
-                const int isv = pc >> 3, piece = pc & 7;
-                const uint16_t *src;
-                if (tiled) {
-                    const uint32_t row = (uint32_t)rs[NW == 4 ? (j & 1) : j];
-                    src = reinterpret_cast<const uint16_t *>(lbj[j]) + ((uint64_t)row * ld_t + dofft);
-                } else {
-                    src = (isv ? vt : kt) + doff[j];
-                }
-                uint16_t *dst = smem + slot * TILE_E + isv * (KVB * KROW) + piece * 512;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    auto dma_one = [&](int t, int slot, int j) __attribute__((always_inline)) {
+        const int pc = wid + NW * j;                           // wave-uniform
+        if (pc < 16) {
+            const int isv = pc >> 3, piece = pc & 7;
+            const uint16_t *src;
+            if (tiled) {
+                const uint32_t row = (uint32_t)rs[NW == 4 ? (j & 1) : j];
+                src = reinterpret_cast<const uint16_t *>(lbj[j]) + ((uint64_t)row * ld_t + dofft);
+            } else {
+                src = (isv ? vbase + t * vstep : kbase + t * kstep) + doff[j];
             }
+            uint16_t *dst = smem + slot * TILE_E + isv * (KVB * KROW) + piece * 512;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
         }
-        if (tiled) win_read(t + 1);                            // in flight until the next call (LDS returns in order)
+    };
+    auto dma_tail = [&](int t) __attribute__((always_inline)) {
+        if (tiled) win_read(t + 1);                            // in flight until the next tile's pieces (LDS returns in order)
+    };
+    auto dma = [&](int t, int slot) __attribute__((always_inline)) {
+        dma_head(t);
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) dma_one(t, slot, j);
+        dma_tail(t);
     };
     const int my_pieces = (16 - wid + NW - 1) / NW;            // this wave's DMA instructions per tile
 
@@ -910,7 +917,7 @@ __global__ void __launch_bounds__(NW * 64, PIPE ? 2 : 3) k_attn32(AttnArgs a) {
             asm volatile("" : "+v"(tg[g]), "+v"(pk[g]));           // computed HERE: the IR sinks unpinned values past B1 to their first use
         };
         // O += V P of one block with the row-sum chain in the gaps (the last group's soft_f first)
-        auto pv = [&](auto neg_tag) __attribute__((always_inline)) {
+        auto pv = [&](auto neg_tag, auto &&after_second) __attribute__((always_inline)) {
             constexpr bool NEG = decltype(neg_tag)::value;
             soft_f(7, neg_tag);
             uint4 u0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), u1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
@@ -921,6 +928,7 @@ __global__ void __launch_bounds__(NW * 64, PIPE ? 2 : 3) k_attn32(AttnArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(va[2], va[3], 0, 1, 2, 3, 4, 5, 6, 7), pf0, o[1], 0, 0, 0);
             ls += tg[2]; ls += tg[3];
+            after_second();
             __builtin_amdgcn_sched_barrier(0);
             o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(va[4], va[5], 0, 1, 2, 3, 4, 5, 6, 7), pf1, o[0], 0, 0, 0);
             ls += tg[4]; ls += tg[5];
@@ -992,12 +1000,14 @@ __global__ void __launch_bounds__(NW * 64, PIPE ? 2 : 3) k_attn32(AttnArgs a) {
                 if (t + 2 < t1) __builtin_amdgcn_s_waitcnt(4 | 0x70);        // tile t+1 landed, the request for t+2 may fly
                 else            __builtin_amdgcn_s_waitcnt(0x0070);
                 __builtin_amdgcn_s_barrier();
-                if (t + 3 < t1) dma(t + 3, (sl + 3) & 3);
+                // tile t+3 into the slot of t-1, one piece at a time over P2 / P3: four back-to-back requests per wave right after a
+                // barrier (16 per workgroup at once) queue up in front of the texture path and hold the waves that issue them
+                if (t + 3 < t1) { dma_head(t + 3); dma_one(t + 3, (sl + 3) & 3, 0); }
                 k_reads(sb1, std::integral_constant<int, 0>{});    // K_A(t+1)
                 __builtin_amdgcn_sched_barrier(0);
             }
             // P2
-            pv(std::false_type{});
+            pv(std::false_type{}, [&]() __attribute__((always_inline)) { if (MORE && t + 3 < t1) dma_one(t + 3, (sl + 3) & 3, 1); });
             // P3
             if (MORE) wait_k();
             v_reads(sb, std::integral_constant<int, 1>{});         // V_B(t)
@@ -1011,12 +1021,14 @@ __global__ void __launch_bounds__(NW * 64, PIPE ? 2 : 3) k_attn32(AttnArgs a) {
                     soft_e(sc1, g);
                     if (g > 0) soft_f(g - 1, neg_tag);
                 }
+                if (MORE && m == NM / 4 && t + 3 < t1) dma_one(t + 3, (sl + 3) & 3, 2);
+                if (MORE && m == NM / 4 + NM / 2 && t + 3 < t1) { dma_one(t + 3, (sl + 3) & 3, 3); dma_tail(t + 3); }
                 __builtin_amdgcn_sched_barrier(0);
             }
             wait_v();
             if (MORE) k_reads(sb1, std::integral_constant<int, 1>{});   // K_B(t+1)
             // P4
-            pv(neg_tag);
+            pv(neg_tag, []() __attribute__((always_inline)) {});
         };
         int t = t0;
         if (TL == 2 && pair_mode) {                                // keys 32..63 of every tile are subtracted
@@ -1502,9 +1514,18 @@ extern "C" size_t lvq_attention_workspace_bytes(int batch, int n_heads, int nq, 
 extern "C" int lvq_attention_stream_ok(int nq, int nkv, int dh) { return plan_k32_waves(nq, nkv, dh, false) != 0; }
 
 namespace {
+constexpr size_t K32_LDS = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16;               // three K+V slots + the redo flag
+constexpr size_t K32_LDS_TILED = K32_LDS + 2 * 8 * KVB * sizeof(int32_t);                  // + two windows of 8 tiles x 64 row words
+constexpr size_t K32_LDS_TILED_PIPE = K32_LDS_TILED + (size_t)2 * KVB * 64 * sizeof(uint16_t);   // the pipelined form's fourth slot
 template <int QS, int TL> void launch_k32_pipe(const AttnArgs &a, int64_t nwg, size_t lds, hipStream_t st) {
     const size_t l = lds + (size_t)2 * KVB * 64 * sizeof(uint16_t);                         // a fourth K+V slot
-    hipFuncSetAttribute((const void *)k_attn32<4, QS, TL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l);
+    static bool attr_set[64] = {};                                                          // per device (the attribute is per device)
+    int devi = 0;
+    hipGetDevice(&devi);
+    if (devi < 0 || devi >= 64 || !attr_set[devi]) {
+        hipFuncSetAttribute((const void *)k_attn32<4, QS, TL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(K32_LDS_TILED_PIPE));
+        if (devi >= 0 && devi < 64) attr_set[devi] = true;
+    }
     hipLaunchKernelGGL((k_attn32<4, QS, TL, true>), dim3((unsigned)nwg), dim3(256), l, st, a);
 }
 template <int TL> void launch_k32(const AttnArgs &a, int nw, int qs, int64_t nwg, size_t lds, hipStream_t st) {
@@ -1525,8 +1546,6 @@ template <int TL> void launch_k32(const AttnArgs &a, int nw, int qs, int64_t nwg
         else         hipLaunchKernelGGL((k_attn32<4, 0, TL>), dim3((unsigned)nwg), dim3(256), lds, st, a);
     }
 }
-constexpr size_t K32_LDS = (size_t)3 * 2 * KVB * 64 * sizeof(uint16_t) + 16;               // three K+V slots + the redo flag
-constexpr size_t K32_LDS_TILED = K32_LDS + 2 * 8 * KVB * sizeof(int32_t);                  // + two windows of 8 tiles x 64 row words
 }  // namespace
 
 // VATLiDAR's cross-attention over the TILED key stream of bev_tiles.hip: batch b attends to n_tiles x 64 keys; key slot r of tile t is row
