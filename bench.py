@@ -292,9 +292,12 @@ def main():
             keys_streamed = int(sum(int(t) * 64 if int(u) else h * w for t, u in pin))
             form += f"; signed pair stream: {keys_streamed} of {S * h * w} keys streamed ({sum(int(u) for _, u in pin)} of {S} scenes signed)"
         ex *= keys_streamed / float(S * h * w)
+        piped = (prec in ("mixed", "mixed16") or os.environ.get("LVQ_ATTN_PIPE")) and not os.environ.get("LVQ_ATTN_NO_PIPE")
+        ring = ("software-pipelined stream (next block's score MFMAs between this block's exponentials), LDS-DMA ring of 4 K|V tiles, 2 waves per SIMD"
+                if piped else "LDS-DMA ring of 3 K|V tiles, 3 waves per SIMD")
         tr, src = profile_traffic([f"k_attn32 S={S} nq={cfg.n_queries} nkv={h * w} {prec}"])
         roofline_attn = {"bound": "mfma", "kernel": f"k_attn32 (VATLiDAR.ca: {S} scenes x {cfg.n_heads} heads x {cfg.n_queries} queries over the {h * w}-key "
-                         "BEV stream, head_dim 64; 32x32x16 MFMA, LDS-DMA ring of 3 K|V tiles, fixed softmax reference); " + form,
+                         "BEV stream, head_dim 64; 32x32x16 MFMA, " + ring + ", fixed softmax reference); " + form,
                          # achieved / frac / flops_per_launch = EXECUTED MFMA FLOPs (keys actually streamed x passes actually issued);
                          # the dense formula of SURVEY 8d (every key of every scene) is reported beside it, not as the roofline number
                          "achieved": round(ach * ex, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach * ex / PEAK_BF16_TFLOPS, 4),

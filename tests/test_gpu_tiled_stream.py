@@ -305,9 +305,10 @@ def test_attention_tiled_signed_falls_back_when_unusable(kind):
 @pytest.mark.parametrize("B,H,nq,n_tiles,fr,qsplit", [(2, 2, 120, 64, 0.35, True), (3, 4, 576, 128, [0.4, 0.9, 0.0], True), (2, 12, 576, 256, [0.2, 0.45], True),
                                                       (1, 2, 120, 67, 0.3, True), (2, 2, 240, 72, 0.3, False)])
 def test_pipelined_stream_is_bit_identical(B, H, nq, n_tiles, fr, qsplit, monkeypatch):
-    """LVQ_ATTN_PIPE=1 selects the software-pipelined form of the long-stream kernel (4 LDS slots, loader-only waves for the query
-    padding).  Same arithmetic in the same order: with the KV split pinned, the tiled stream, the per-model totals and the signed
-    pair stream (pair lists of any length, full-list batches, 1 .. n tiles per split) equal the default form bit for bit."""
+    """The software-pipelined form of the long-stream kernel (4 LDS slots, loader-only waves for the query padding; the default for
+    split / fp16 queries, LVQ_ATTN_PIPE=1 forces it for plain ones) against the plain form (LVQ_ATTN_NO_PIPE=1).  Same arithmetic in
+    the same order: with the KV split pinned, the tiled stream, the per-model totals and the signed pair stream (pair lists of any
+    length, full-list batches, 1 .. n tiles per split) are equal bit for bit."""
     o = ops()
     kv, src, _ = _row_case(B, H, n_tiles, fr, 31)
     srcd = src.to(DEV).contiguous()
@@ -315,10 +316,8 @@ def test_pipelined_stream_is_bit_identical(B, H, nq, n_tiles, fr, qsplit, monkey
     d = H * 64
     res = {}
     for pipe in (False, True):
-        if pipe:
-            monkeypatch.setenv("LVQ_ATTN_PIPE", "1")
-        else:
-            monkeypatch.delenv("LVQ_ATTN_PIPE", raising=False)
+        monkeypatch.delenv("LVQ_ATTN_NO_PIPE" if pipe else "LVQ_ATTN_PIPE", raising=False)
+        monkeypatch.setenv("LVQ_ATTN_PIPE" if pipe else "LVQ_ATTN_NO_PIPE", "1")
         out = {}
         for ns in ("1", "3", "8"):
             if 8 * int(ns) > n_tiles:
@@ -341,6 +340,8 @@ def test_pipelined_stream_is_bit_identical(B, H, nq, n_tiles, fr, qsplit, monkey
                                                                    dh=64, scale=0.125, shared_q=True, k_fp16=True)
         res[pipe] = out
     monkeypatch.delenv("LVQ_ATTN_NSPLIT", raising=False)
+    monkeypatch.delenv("LVQ_ATTN_PIPE", raising=False)
+    monkeypatch.delenv("LVQ_ATTN_NO_PIPE", raising=False)
     assert res[False].keys() == res[True].keys() and len(res[True]) > 0
     for k in res[False]:
         for a, b in zip(res[False][k], res[True][k]):

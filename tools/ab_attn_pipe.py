@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of the long-stream attention kernel: the default form against the software-pipelined one (LVQ_ATTN_PIPE=1), same inputs,
+"""A/B of the long-stream attention kernel: the plain form (LVQ_ATTN_NO_PIPE=1) against the software-pipelined one (LVQ_ATTN_PIPE=1), same inputs,
 outputs compared bit for bit, both timed.  Shapes as in the bench (B scenes x 12 heads x 576 queries x 4096 tiles), q hi + lo."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,19 +19,19 @@ def ab(name, fn, flops):
     """Outputs with the KV split pinned (same partial sums in both forms -> bit-identical), times with each form's own plan."""
     res = {}
     for mode in ("0", "1"):
-        os.environ.pop("LVQ_ATTN_PIPE", None)
-        if mode == "1": os.environ["LVQ_ATTN_PIPE"] = "1"
+        os.environ.pop("LVQ_ATTN_PIPE", None); os.environ.pop("LVQ_ATTN_NO_PIPE", None)
+        os.environ["LVQ_ATTN_PIPE" if mode == "1" else "LVQ_ATTN_NO_PIPE"] = "1"
         os.environ["LVQ_ATTN_NSPLIT"] = "8"
         out = fn(); torch.cuda.synchronize()
         outs = [o.clone() for o in out if o is not None] if isinstance(out, (tuple, list)) else [out.clone()]
         os.environ.pop("LVQ_ATTN_NSPLIT")
         res[mode] = (outs, timeit(fn))
-    os.environ.pop("LVQ_ATTN_PIPE", None)
+    os.environ.pop("LVQ_ATTN_PIPE", None); os.environ.pop("LVQ_ATTN_NO_PIPE", None)
     same = all(torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b)
                for a, b in zip(res["0"][0], res["1"][0]))
     dmax = max(float((a.float() - b.float()).abs().max()) for a, b in zip(res["0"][0], res["1"][0]))
     t0, t1 = res["0"][1], res["1"][1]
-    print(f"{name:40s} default {t0:8.3f} ms ({flops / t0 / 1e9:7.1f} TF)  pipelined {t1:8.3f} ms ({flops / t1 / 1e9:7.1f} TF)  "
+    print(f"{name:40s} plain {t0:8.3f} ms ({flops / t0 / 1e9:7.1f} TF)  pipelined {t1:8.3f} ms ({flops / t1 / 1e9:7.1f} TF)  "
           f"bit-identical {same}  max|diff| {dmax:.3e}", flush=True)
     return same
 q1 = ops.cast(torch.randn(nq, d, device=DEV), True)
