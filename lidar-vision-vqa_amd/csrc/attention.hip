@@ -1315,13 +1315,13 @@ int plan_k32_waves(int nq, int nkv, int dh, bool split) {      // split = K / V 
     }
     return 0;
 }
-// the pipelined form of k_attn32 (2 workgroups per CU) is the default for 4 waves and a split (hi + lo) or fp16 query: bit-identical to
-// the other form, same-box +4-10 % on the signed stream and +2.5 % on the bench step.  With a plain query a block has 4 score MFMAs for
-// the same 16 exponentials and it measured 0-5 % slower: not used there.  LVQ_ATTN_NO_PIPE=1 / LVQ_ATTN_PIPE=1 force one form for every
+// the pipelined form of k_attn32 (2 workgroups per CU) is the default for 4 waves and a split (hi + lo) query: bit-identical to the
+// other form, same-box +4-10 % on the signed stream and +2.5 % on the bench step.  With a plain or single-fp16 query a block has 4 score
+// MFMAs for the same 16 exponentials and it measured 0-5 % slower (mixed16 bench step -1 %): not used there.  LVQ_ATTN_NO_PIPE=1 / LVQ_ATTN_PIPE=1 force one form for every
 // query kind (A/B: tools/ab_attn_pipe.py; DESIGN 3.2 has the measurements)
 bool k32_pipe(int nw, int qs) {
     if (nw != 4 || getenv("LVQ_ATTN_NO_PIPE") != nullptr) return false;
-    return qs != 0 || getenv("LVQ_ATTN_PIPE") != nullptr;
+    return qs == 1 || getenv("LVQ_ATTN_PIPE") != nullptr;
 }
 AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, bool allow32 = false, int qs = 0) {
     AttnPlan p;
