@@ -222,6 +222,7 @@ __global__ void __launch_bounds__(BIN_BLOCK) k_bin_scatter(const float *__restri
 constexpr int SLAB_NT = 1024;     // threads per slab workgroup (dense slabs set the tail; 256 threads were 2x slower)
 
 // ---- block-wide exclusive scan helper (blockDim.x = SLAB_NT) ----
+template <int NT = SLAB_NT>
 __device__ __forceinline__ int block_excl_scan256(int v, int *wave_tot, int &total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int incl = v;
@@ -234,7 +235,7 @@ __device__ __forceinline__ int block_excl_scan256(int v, int *wave_tot, int &tot
     __syncthreads();
     int wbase = 0, tot = 0;
 #pragma unroll
-    for (int w = 0; w < SLAB_NT / 64; ++w) {
+    for (int w = 0; w < NT / 64; ++w) {
         const int t = wave_tot[w];
         if (w < wid) wbase += t;
         tot += t;
@@ -260,11 +261,12 @@ __device__ __forceinline__ int popc_below(uint64_t m, int bit) {
     return __popcll(m & ((bit == 0) ? 0ull : (~0ull >> (64 - bit))));
 }
 
+constexpr int DYN_NT = 512;       // threads per slab workgroup of the dynamic path (four workgroups per CU instead of two at 1024)
 // ---- dynamic pass B: occupied cells per slab ----
-__global__ void __launch_bounds__(SLAB_NT) k_dyn_slab_count(BinCfg cfg, const int32_t *__restrict__ gstart,
+__global__ void __launch_bounds__(DYN_NT) k_dyn_slab_count(BinCfg cfg, const int32_t *__restrict__ gstart,
                                                         const int32_t *__restrict__ soff, int32_t *__restrict__ slab_cnt) {
     extern __shared__ unsigned long long bm[];
-    __shared__ int wave_tot[SLAB_NT / 64];
+    __shared__ int wave_tot[DYN_NT / 64];
     const int s = blockIdx.x;
     const int p0 = gstart[s], p1 = gstart[s + 1];
     if (p0 == p1) {
@@ -272,45 +274,45 @@ __global__ void __launch_bounds__(SLAB_NT) k_dyn_slab_count(BinCfg cfg, const in
         return;
     }
     const int nw = 1 << (cfg.logslab - 6);
-    for (int w = threadIdx.x; w < nw; w += SLAB_NT) bm[w] = 0ull;
+    for (int w = threadIdx.x; w < nw; w += DYN_NT) bm[w] = 0ull;
     __syncthreads();
-    for (int p = p0 + threadIdx.x; p < p1; p += SLAB_NT) {
+    for (int p = p0 + threadIdx.x; p < p1; p += DYN_NT) {
         const int off = soff[p];
         atomicOr(&bm[off >> 6], 1ull << (off & 63));
     }
     __syncthreads();
     int c = 0;
-    for (int w = threadIdx.x; w < nw; w += SLAB_NT) c += __popcll(bm[w]);
+    for (int w = threadIdx.x; w < nw; w += DYN_NT) c += __popcll(bm[w]);
     int tot;
-    block_excl_scan256(c, wave_tot, tot);
+    block_excl_scan256<DYN_NT>(c, wave_tot, tot);
     if (threadIdx.x == 0) slab_cnt[s] = tot;
 }
 
 constexpr int DYN_VCAP = 4096;   // per-slab voxel counters held in LDS
 
 // ---- dynamic pass B': ranks, inverse map, sequential unique outputs ----
-__global__ void __launch_bounds__(SLAB_NT) k_dyn_slab_write(BinCfg cfg, Geom g, const int32_t *__restrict__ gstart,
+__global__ void __launch_bounds__(DYN_NT) k_dyn_slab_write(BinCfg cfg, Geom g, const int32_t *__restrict__ gstart,
                                                         const int32_t *__restrict__ sidx, const int32_t *__restrict__ soff,
                                                         const int32_t *__restrict__ slab_cnt, int32_t *__restrict__ unq_inv,
                                                         int32_t *__restrict__ unq_key, int32_t *__restrict__ unq_cnt,
                                                         int32_t *__restrict__ coords_bzyx, int32_t *__restrict__ m_out) {
     extern __shared__ unsigned long long smem64[];
-    __shared__ int wave_tot[SLAB_NT / 64];
+    __shared__ int wave_tot[DYN_NT / 64];
     const int s = blockIdx.x;
     const int p0 = gstart[s], p1 = gstart[s + 1];
     if (p0 == p1 && s != 0) return;
     // first voxel of this slab = occupied cells of all slabs before it: every block sums the <= 8192 per-slab counts itself
     // (no single-workgroup scan kernel in between); block 0 also publishes the total M
     int before = 0, all = 0;
-    for (int b = threadIdx.x; b < cfg.nslabs; b += SLAB_NT) {
+    for (int b = threadIdx.x; b < cfg.nslabs; b += DYN_NT) {
         const int v = slab_cnt[b];
         all += v;
         if (b < s) before += v;
     }
     int vbase, total;
-    block_excl_scan256(before, wave_tot, vbase);
+    block_excl_scan256<DYN_NT>(before, wave_tot, vbase);
     if (s == 0) {
-        block_excl_scan256(all, wave_tot, total);
+        block_excl_scan256<DYN_NT>(all, wave_tot, total);
         if (threadIdx.x == 0) *m_out = total;
         if (p0 == p1) return;
     }
@@ -321,33 +323,33 @@ __global__ void __launch_bounds__(SLAB_NT) k_dyn_slab_write(BinCfg cfg, Geom g, 
     int32_t *cnt_l = wpre + nw;                                    // [DYN_VCAP]
     const bool lds_cnt = nvox <= DYN_VCAP;
     if (!lds_cnt) {                                   // oversized slab: counters live in this slab's range of unq_cnt
-        for (int v = threadIdx.x; v < nvox; v += SLAB_NT) unq_cnt[vbase + v] = 0;
+        for (int v = threadIdx.x; v < nvox; v += DYN_NT) unq_cnt[vbase + v] = 0;
         __threadfence();
     }
-    for (int w = threadIdx.x; w < nw; w += SLAB_NT) bm[w] = 0ull;
-    for (int v = threadIdx.x; v < DYN_VCAP; v += SLAB_NT) cnt_l[v] = 0;
+    for (int w = threadIdx.x; w < nw; w += DYN_NT) bm[w] = 0ull;
+    for (int v = threadIdx.x; v < DYN_VCAP; v += DYN_NT) cnt_l[v] = 0;
     __syncthreads();
-    for (int p = p0 + threadIdx.x; p < p1; p += SLAB_NT) {
+    for (int p = p0 + threadIdx.x; p < p1; p += DYN_NT) {
         const int off = soff[p];
         atomicOr(&bm[off >> 6], 1ull << (off & 63));
     }
     __syncthreads();
     // exclusive popcount scan over the bitmap words (thread t owns words t*per .. t*per+per-1)
-    const int per = (nw + SLAB_NT - 1) / SLAB_NT;
+    const int per = (nw + DYN_NT - 1) / DYN_NT;
     int c = 0;
     for (int j = 0; j < per; ++j) {
         const int w = threadIdx.x * per + j;
         if (w < nw) c += __popcll(bm[w]);
     }
     int tot;
-    int ex = block_excl_scan256(c, wave_tot, tot);
+    int ex = block_excl_scan256<DYN_NT>(c, wave_tot, tot);
     for (int j = 0; j < per; ++j) {
         const int w = threadIdx.x * per + j;
         if (w < nw) { wpre[w] = ex; ex += __popcll(bm[w]); }
     }
     __syncthreads();
     // per point: rank of its voxel, inverse map, count
-    for (int p = p0 + threadIdx.x; p < p1; p += SLAB_NT) {
+    for (int p = p0 + threadIdx.x; p < p1; p += DYN_NT) {
         const int off = soff[p];
         const int lr = wpre[off >> 6] + popc_below(bm[off >> 6], off & 63);
         unq_inv[sidx[p]] = vbase + lr;
@@ -698,10 +700,10 @@ int lvq_binned_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_si
                        (const int32_t *)nullptr, w.gstart, w.cursor, w.sidx, w.soff, (float4 *)nullptr, (const int32_t *)w.ghist,
                        &counts[1]);
     const int nw = 1 << (cfg.logslab - 6);
-    hipLaunchKernelGGL(k_dyn_slab_count, dim3(cfg.nslabs), dim3(SLAB_NT), sizeof(unsigned long long) * nw, st, cfg, w.gstart, w.soff,
+    hipLaunchKernelGGL(k_dyn_slab_count, dim3(cfg.nslabs), dim3(DYN_NT), sizeof(unsigned long long) * nw, st, cfg, w.gstart, w.soff,
                        w.slab_cnt);
     const size_t lds = sizeof(unsigned long long) * nw + sizeof(int32_t) * nw + sizeof(int32_t) * DYN_VCAP;
-    hipLaunchKernelGGL(k_dyn_slab_write, dim3(cfg.nslabs), dim3(SLAB_NT), lds, st, cfg, g, w.gstart, w.sidx, w.soff, w.slab_cnt, unq_inv,
+    hipLaunchKernelGGL(k_dyn_slab_write, dim3(cfg.nslabs), dim3(DYN_NT), lds, st, cfg, g, w.gstart, w.sidx, w.soff, w.slab_cnt, unq_inv,
                        unq_key, unq_cnt, coords_bzyx, &counts[0]);
     return lvq_launch_status();
 }
