@@ -287,6 +287,8 @@ int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_
  *   lvq_bev_scene_pairs: pair_src [batch, cap_tiles, 64], pair_info [batch, 2] from lvq_bev_tiles' row_src -- tile j of a batch holds
  *       its dirty rows 32 j .. 32 j + 31 (keys 0..31, added) and the table rows of the same cells (keys 32..63, subtracted);
  *       pair_info[2 b] = pair tiles, pair_info[2 b + 1] = 1 when that is shorter than the full stream (else the batch runs row_src).
+ *       Contents of pair_src beyond a batch's list are unspecified (with cap_tiles >= n_tiles the last tile slot of every batch is
+ *       scratch of the call: a list that is used has fewer than n_tiles tiles).
  *   lvq_attention_bf16_tiled_signed: as lvq_attention_bf16_tiled (same q as the totals; q_bstride = 0 shares one copy).  A
  *       (batch, head) whose signed row sum is not finite or below 1/16 of the table total is redone over its full stream by a
  *       predicated second launch.  Not bit-identical to the full stream (fp32 accumulation order); same operand roundings. */

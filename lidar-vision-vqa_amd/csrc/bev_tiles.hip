@@ -229,6 +229,91 @@ __global__ void __launch_bounds__(PAIR_NT) k_scene_pairs(const int32_t *__restri
     if (tid == 0) { pair_info[2 * s] = use ? n_pt : 0; pair_info[2 * s + 1] = use ? 1 : 0; }
 }
 
+// The same lists from many workgroups per scene (one workgroup per scene walks 262 144 words in 64 dependent rounds: 123 us of a 20 ms
+// step at 32 scenes).  A scene is cut into <= 64 chunks of whole 1024-word rounds; pass 1 counts the dirty rows per chunk, pass 2 gives
+// every chunk its starting position (the sum of the counts before it) and compacts it.  The chunk counts live in the LAST tile slot of
+// the scene's list (cap >= nt: a list that is used has fewer than nt tiles, so that slot is never part of one); entries are written
+// for positions below (cap - 1) * 32 only.
+constexpr int PAIR2_NT = 256;
+__global__ void __launch_bounds__(PAIR2_NT) k_scene_pair_count(const int32_t *__restrict__ row_src, int nt, int row_base, int cap, int chunk,
+                                                               int32_t *__restrict__ pair_src) {
+    __shared__ int wsum[PAIR2_NT / 64];
+    const int ch = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ne = nt * TCELLS;
+    const int32_t *src = row_src + (int64_t)s * ne;
+    const int e_end = (ch + 1) * chunk < ne ? (ch + 1) * chunk : ne;
+    int c = 0;
+    for (int e = ch * chunk + tid * 4; e < e_end; e += PAIR2_NT * 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(src + e);
+        c += (v.x >= row_base) + (v.y >= row_base) + (v.z >= row_base) + (v.w >= row_base);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) wsum[wid] = c;
+    __syncthreads();
+    if (tid == 0) pair_src[((int64_t)s * cap + (cap - 1)) * TCELLS + ch] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ void __launch_bounds__(PAIR2_NT) k_scene_pair_write(const int32_t *__restrict__ row_src, int nt, int row_base, int cap, int chunk, int nch,
+                                                               int32_t *__restrict__ pair_src, int32_t *__restrict__ pair_info) {
+    __shared__ int wsum[PAIR2_NT / 64];
+    __shared__ int l_start[2];
+    const int ch = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ne = nt * TCELLS;
+    const int32_t *src = row_src + (int64_t)s * ne;
+    int32_t *dst = pair_src + (int64_t)s * cap * TCELLS;
+    if (tid < 64) {                                              // start = dirty rows of the chunks before this one, total = of all
+        const int v = tid < nch ? dst[(int64_t)(cap - 1) * TCELLS + tid] : 0;
+        int before = tid < ch ? v : 0, all = v;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
+        if (tid == 0) { l_start[0] = before; l_start[1] = all; }
+    }
+    __syncthreads();
+    int run = l_start[0];
+    const int n_dirty = l_start[1];
+    const int lim = (cap - 1) * 32;
+    const int e_end = (ch + 1) * chunk < ne ? (ch + 1) * chunk : ne;
+    for (int e0 = ch * chunk; e0 < e_end; e0 += PAIR2_NT * 4) {
+        const int e = e0 + tid * 4;
+        int4 v = make_int4(0, 0, 0, 0);
+        if (e < e_end) v = *reinterpret_cast<const int4 *>(src + e);
+        const int32_t vv[4] = {v.x, v.y, v.z, v.w};
+        int c = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c += (e < e_end && vv[u] >= row_base) ? 1 : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(inc, o); if (lane >= o) inc += n; }
+        __syncthreads();                                         // (wsum of the previous round has been read)
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        int wb = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < PAIR2_NT / 64; ++q) { if (q < wid) wb += wsum[q]; tot += wsum[q]; }
+        int j = run + wb + inc - c;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e < e_end && vv[u] >= row_base) {
+                if (j < lim) {
+                    dst[(j >> 5) * TCELLS + (j & 31)] = vv[u];
+                    dst[(j >> 5) * TCELLS + 32 + (j & 31)] = e + u;
+                }
+                ++j;
+            }
+        run += tot;
+    }
+    if (ch == 0) {
+        const int n_pt = (n_dirty + 31) >> 5;
+        const bool use = n_pt < nt && n_pt <= cap - 1;
+        if (use && tid < 32 && n_dirty + tid < n_pt * 32) {       // padding of the last pair tile
+            const int j = n_dirty + tid;
+            dst[(j >> 5) * TCELLS + (j & 31)] = 0;
+            dst[(j >> 5) * TCELLS + 32 + (j & 31)] = 0;
+        }
+        if (tid == 0) { pair_info[2 * s] = use ? n_pt : 0; pair_info[2 * s + 1] = use ? 1 : 0; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // fused token kernel.  512 threads = 8 waves; persistent over the live list.  A work item ("group") = 8 consecutive live pieces =
 // 64 rows = four 16-row MFMA groups; its pieces may belong to different tiles / scenes, each brings its own 4 x 6 halo.
@@ -1376,6 +1461,18 @@ extern "C" int lvq_bev_scene_pairs(const int32_t *row_src, int batch, int n_tile
                                    int32_t *pair_info, lvq_stream_t stream) {
     if (!row_src || !pair_src || !pair_info || batch <= 0 || n_tiles <= 0 || cap_tiles <= 0 || row_base < 0) return LVQ_EINVAL;
     if (((uintptr_t)row_src & 15) || (int64_t)n_tiles * bt::TCELLS > 0x7fffffff || batch > 65535) return LVQ_EUNSUPPORTED;
+    if (cap_tiles >= n_tiles && cap_tiles >= 2 && getenv("LVQ_PAIRS_ONE_WG") == nullptr) {
+        // many workgroups per scene: <= 64 chunks of whole 1024-word rounds; the chunk counts use the list's last tile slot as scratch
+        const int64_t ne = (int64_t)n_tiles * bt::TCELLS;
+        int64_t chunk = (ne + 63) / 64;
+        chunk = (chunk + 1023) / 1024 * 1024;
+        const int nch = (int)((ne + chunk - 1) / chunk);
+        hipLaunchKernelGGL(bt::k_scene_pair_count, dim3(nch, batch), dim3(bt::PAIR2_NT), 0, lvq_s(stream), row_src, n_tiles, row_base, cap_tiles, (int)chunk,
+                           pair_src);
+        hipLaunchKernelGGL(bt::k_scene_pair_write, dim3(nch, batch), dim3(bt::PAIR2_NT), 0, lvq_s(stream), row_src, n_tiles, row_base, cap_tiles, (int)chunk,
+                           nch, pair_src, pair_info);
+        return lvq_launch_status();
+    }
     hipLaunchKernelGGL(bt::k_scene_pairs, dim3(batch), dim3(bt::PAIR_NT), 0, lvq_s(stream), row_src, n_tiles, row_base, cap_tiles, pair_src, pair_info);
     return lvq_launch_status();
 }

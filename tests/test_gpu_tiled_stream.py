@@ -216,11 +216,17 @@ def test_attention_tiled_equals_dense_on_gathered_rows(B, H, nq, n_tiles, qsplit
         assert torch.equal(got[1], ref[1])
 
 
-def test_scene_pairs_vs_numpy():
+@pytest.mark.parametrize("one_wg", [False, True])
+@pytest.mark.parametrize("B,nt,fr", [(4, 96, [0.3, 0.0, 0.7, 0.05]), (3, 1100, [0.27, 0.49, 0.002])])
+def test_scene_pairs_vs_numpy(B, nt, fr, one_wg, monkeypatch):
+    """Pair lists from the chunked two-kernel form (many workgroups per scene, the default) and from the one-workgroup-per-scene form."""
+    if one_wg:
+        monkeypatch.setenv("LVQ_PAIRS_ONE_WG", "1")
+    else:
+        monkeypatch.delenv("LVQ_PAIRS_ONE_WG", raising=False)
     o = ops()
-    B, nt = 4, 96
     hw = nt * 64
-    _, src, _ = _row_case(B, 2, nt, [0.3, 0.0, 0.7, 0.05], 3)
+    _, src, _ = _row_case(B, 2, nt, fr, 3)
     pair_src, pair_info = o.bev_scene_pairs(src.to(DEV).contiguous(), B, nt, hw)
     ps, pi = pair_src.cpu().numpy(), pair_info.cpu().numpy()
     s_np = src.numpy()
