@@ -206,16 +206,33 @@ __global__ void __launch_bounds__(256) k_pillar_vfe1(const float4 *__restrict__ 
         dst[2] = live ? make_float4(f[8], f[9], f[10], f[11]) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     wave_sync();
+    // the loop is bound by its LDS broadcast reads (every lane the same 16 bytes: 4 LDS cycles each).  With <= 10 input features --
+    // the PointPillars default -- the third read of a point is 8 bytes and the two products with zero weights and zero features
+    // (exactly + 0) are not issued
     float mx = -INFINITY;
+    if (cin <= 10) {
 #pragma unroll 4
-    for (int j = 0; j < T; ++j) {
-        const float4 *src = reinterpret_cast<const float4 *>(&feat[wid][j][0]);
-        const float4 a = src[0], b = src[1], c4 = src[2];
-        float acc = 0.f;
-        acc = fmaf(a.x, wreg[0], acc); acc = fmaf(a.y, wreg[1], acc); acc = fmaf(a.z, wreg[2], acc); acc = fmaf(a.w, wreg[3], acc);
-        acc = fmaf(b.x, wreg[4], acc); acc = fmaf(b.y, wreg[5], acc); acc = fmaf(b.z, wreg[6], acc); acc = fmaf(b.w, wreg[7], acc);
-        acc = fmaf(c4.x, wreg[8], acc); acc = fmaf(c4.y, wreg[9], acc); acc = fmaf(c4.z, wreg[10], acc); acc = fmaf(c4.w, wreg[11], acc);
-        mx = fmaxf(mx, fmaxf(acc * sc + sh, 0.f));
+        for (int j = 0; j < T; ++j) {
+            const float4 *src = reinterpret_cast<const float4 *>(&feat[wid][j][0]);
+            const float4 a = src[0], b = src[1];
+            const float2 c2 = *reinterpret_cast<const float2 *>(&feat[wid][j][8]);
+            float acc = 0.f;
+            acc = fmaf(a.x, wreg[0], acc); acc = fmaf(a.y, wreg[1], acc); acc = fmaf(a.z, wreg[2], acc); acc = fmaf(a.w, wreg[3], acc);
+            acc = fmaf(b.x, wreg[4], acc); acc = fmaf(b.y, wreg[5], acc); acc = fmaf(b.z, wreg[6], acc); acc = fmaf(b.w, wreg[7], acc);
+            acc = fmaf(c2.x, wreg[8], acc); acc = fmaf(c2.y, wreg[9], acc);
+            mx = fmaxf(mx, fmaxf(acc * sc + sh, 0.f));
+        }
+    } else {
+#pragma unroll 4
+        for (int j = 0; j < T; ++j) {
+            const float4 *src = reinterpret_cast<const float4 *>(&feat[wid][j][0]);
+            const float4 a = src[0], b = src[1], c4 = src[2];
+            float acc = 0.f;
+            acc = fmaf(a.x, wreg[0], acc); acc = fmaf(a.y, wreg[1], acc); acc = fmaf(a.z, wreg[2], acc); acc = fmaf(a.w, wreg[3], acc);
+            acc = fmaf(b.x, wreg[4], acc); acc = fmaf(b.y, wreg[5], acc); acc = fmaf(b.z, wreg[6], acc); acc = fmaf(b.w, wreg[7], acc);
+            acc = fmaf(c4.x, wreg[8], acc); acc = fmaf(c4.y, wreg[9], acc); acc = fmaf(c4.z, wreg[10], acc); acc = fmaf(c4.w, wreg[11], acc);
+            mx = fmaxf(mx, fmaxf(acc * sc + sh, 0.f));
+        }
     }
     if (act) out[v * cout + lane] = mx;
 }
