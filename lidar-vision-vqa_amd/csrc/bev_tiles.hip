@@ -83,7 +83,7 @@ __device__ __forceinline__ unsigned piece_mask(const int32_t *__restrict__ idx, 
 
 // ---- pass 1: live pieces and dirty rows per block of CNT_BLOCK flat indices: block_cnt[2 b] / [2 b + 1] ----
 __global__ void __launch_bounds__(256) k_piece_count(const int32_t *__restrict__ idx, int S, int H, int W, int force, int64_t total,
-                                                     int32_t *__restrict__ block_cnt) {
+                                                     int32_t *__restrict__ block_cnt, uint8_t *__restrict__ masks) {
     __shared__ int wsum[4][2];
     int c = 0, dcount = 0;
 #pragma unroll
@@ -91,6 +91,7 @@ __global__ void __launch_bounds__(256) k_piece_count(const int32_t *__restrict__
         const int64_t i = (int64_t)blockIdx.x * CNT_BLOCK + u * 256 + threadIdx.x;
         if (i < total) {
             const unsigned m = piece_mask(idx, i, S, H, W, force);
+            masks[i] = (uint8_t)m;                                // pass 2 reads the byte instead of the 24 halo words again
             c += m ? 1 : 0;
             dcount += __popc(m);
         }
@@ -113,8 +114,9 @@ __global__ void __launch_bounds__(256) k_piece_count(const int32_t *__restrict__
 //   row_src[s * HW + 64 t + 8 p + j] = row_base + (dirty-row number) for a dirty cell, 64 t + 8 p + j (its row in the table) otherwise
 //   counts[0] = live pieces, counts[1] = rows of the live pieces (8 x), counts[2] = dirty rows, by the last block
 __global__ void __launch_bounds__(256) k_piece_compact(const int32_t *__restrict__ idx, int S, int H, int W, int force, int64_t total,
-                                                       const int32_t *__restrict__ block_cnt, int nblocks, int row_base, int32_t *__restrict__ live_list,
-                                                       int2 *__restrict__ piece_dirty, int32_t *__restrict__ row_src, int32_t *__restrict__ counts) {
+                                                       const int32_t *__restrict__ block_cnt, const uint8_t *__restrict__ masks, int nblocks, int row_base,
+                                                       int32_t *__restrict__ live_list, int2 *__restrict__ piece_dirty, int32_t *__restrict__ row_src,
+                                                       int32_t *__restrict__ counts) {
     __shared__ int wsum[4][2];
     __shared__ int l_base[2];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -134,7 +136,7 @@ __global__ void __launch_bounds__(256) k_piece_compact(const int32_t *__restrict
     const int64_t hw = (int64_t)H * W;
     for (int u = 0; u < CNT_BLOCK / 256; ++u) {
         const int64_t i = (int64_t)blockIdx.x * CNT_BLOCK + u * 256 + tid;
-        const unsigned msk = i < total ? piece_mask(idx, i, S, H, W, force) : 0u;
+        const unsigned msk = i < total ? (unsigned)masks[i] : 0u;
         const bool live = msk != 0;
         const unsigned long long bal = __ballot(live);
         const int nd = __popc(msk);
@@ -1331,7 +1333,7 @@ __global__ void __launch_bounds__(512) k_kv_rows(KvRowArgs a) {
 extern "C" size_t lvq_bev_tiles_workspace_bytes(int batch, int ny, int nx) {
     if (batch <= 0 || ny <= 0 || nx <= 0) return 0;
     const int64_t total = (int64_t)batch * (ny / 8) * (nx / 8) * bt::NPIECE;
-    return lvq_align((size_t)2 * lvq_cdiv(total, bt::CNT_BLOCK) * sizeof(int32_t)) + 512;      // (live pieces, dirty rows) per counting block
+    return lvq_align((size_t)2 * lvq_cdiv(total, bt::CNT_BLOCK) * sizeof(int32_t)) + lvq_align((size_t)total) + 512;   // (live pieces, dirty rows) per counting block + one mask byte per piece
 }
 
 extern "C" int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, int force_all, int row_base, int32_t *live_list,
@@ -1344,11 +1346,12 @@ extern "C" int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, 
     const int nb = (int)((total + bt::CNT_BLOCK - 1) / bt::CNT_BLOCK);
     LvqArena arena(ws, ws_bytes);
     int32_t *block_cnt = arena.take<int32_t>((size_t)2 * nb);
+    uint8_t *masks = arena.take<uint8_t>((size_t)total);
     if (!arena.ok) return LVQ_EWORKSPACE;
     hipStream_t st = lvq_s(stream);
-    hipLaunchKernelGGL(bt::k_piece_count, dim3(nb), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, total, block_cnt);
-    hipLaunchKernelGGL(bt::k_piece_compact, dim3(nb), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, total, (const int32_t *)block_cnt, nb,
-                       row_base, live_list, reinterpret_cast<int2 *>(piece_dirty), row_src, counts);
+    hipLaunchKernelGGL(bt::k_piece_count, dim3(nb), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, total, block_cnt, masks);
+    hipLaunchKernelGGL(bt::k_piece_compact, dim3(nb), dim3(256), 0, st, idx_map, batch, ny, nx, force_all, total, (const int32_t *)block_cnt,
+                       (const uint8_t *)masks, nb, row_base, live_list, reinterpret_cast<int2 *>(piece_dirty), row_src, counts);
     return lvq_launch_status();
 }
 
