@@ -64,11 +64,12 @@ __device__ __forceinline__ unsigned piece_mask(const int32_t *__restrict__ idx, 
         occ[r] = 0;
         const int gy = y0 - 1 + r;
         if (gy < 0 || gy >= H) continue;
-#pragma unroll
-        for (int c = 0; c < PW; ++c) {
-            const int gx = x0 - 1 + c;
-            if (gx >= 0 && gx < W && plane[(int64_t)gy * W + gx] >= 0) occ[r] |= 1u << c;
-        }
+        // columns x0 .. x0 + 3 are one aligned 16-byte word (x0 and W are multiples of 4), the two flanks single words
+        const int32_t *row = plane + (int64_t)gy * W + x0;
+        const int4 mid = *reinterpret_cast<const int4 *>(row);
+        occ[r] = (mid.x >= 0 ? 2u : 0u) | (mid.y >= 0 ? 4u : 0u) | (mid.z >= 0 ? 8u : 0u) | (mid.w >= 0 ? 16u : 0u);
+        if (x0 > 0 && row[-1] >= 0) occ[r] |= 1u;
+        if (x0 + 4 < W && row[4] >= 0) occ[r] |= 32u;
     }
     unsigned m = 0;
 #pragma unroll
@@ -1342,7 +1343,7 @@ extern "C" int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, 
     if ((ny % bt::TS) || (nx % bt::TS)) return LVQ_EUNSUPPORTED;
     const int64_t total = (int64_t)batch * (ny / bt::TS) * (nx / bt::TS) * bt::NPIECE;
     if ((int64_t)row_base + total * bt::PCELLS > 0x7fffffff || batch > 65535) return LVQ_EUNSUPPORTED;      // rows are int32
-    if (((uintptr_t)row_src & 15) || ((uintptr_t)piece_dirty & 7)) return LVQ_EUNSUPPORTED;
+    if (((uintptr_t)row_src & 15) || ((uintptr_t)piece_dirty & 7) || ((uintptr_t)idx_map & 15)) return LVQ_EUNSUPPORTED;
     const int nb = (int)((total + bt::CNT_BLOCK - 1) / bt::CNT_BLOCK);
     LvqArena arena(ws, ws_bytes);
     int32_t *block_cnt = arena.take<int32_t>((size_t)2 * nb);
