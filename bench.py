@@ -292,7 +292,7 @@ def main():
             keys_streamed = int(sum(int(t) * 64 if int(u) else h * w for t, u in pin))
             form += f"; signed pair stream: {keys_streamed} of {S * h * w} keys streamed ({sum(int(u) for _, u in pin)} of {S} scenes signed)"
         ex *= keys_streamed / float(S * h * w)
-        piped = (prec == "mixed" or os.environ.get("LVQ_ATTN_PIPE")) and not os.environ.get("LVQ_ATTN_NO_PIPE")
+        piped = (prec in ("mixed", "mixed16") or os.environ.get("LVQ_ATTN_PIPE")) and not os.environ.get("LVQ_ATTN_NO_PIPE")
         ring = ("software-pipelined stream (next block's score MFMAs between this block's exponentials), LDS-DMA ring of 4 K|V tiles, 2 waves per SIMD"
                 if piped else "LDS-DMA ring of 3 K|V tiles, 3 waves per SIMD")
         tr, src = profile_traffic([f"k_attn32 S={S} nq={cfg.n_queries} nkv={h * w} {prec}"])

@@ -881,7 +881,9 @@ __global__ void __launch_bounds__(NW * 64, PIPE ? 2 : 3) k_attn32(AttnArgs a) {
     [[maybe_unused]] auto stream_pipe = [&]() __attribute__((always_inline)) {
         if (!(t0 < t1)) return;
         constexpr int NM = (QS == 1 || QS == 3) ? 8 : 4;           // score MFMAs per 32-key block
-        constexpr int GPM = 8 / NM;                                // exp groups (2 scores each) per MFMA gap
+        // softmax groups (2 scores each) of the finished block per score-MFMA gap: group g runs in gap m with slot_lo(m) <= g < slot_lo(m + 1)
+        // (NM == 8: one per gap; NM == 4: 2, 1, 2, 1 -- the last two groups run in the PV gaps, see pv)
+        auto slot_lo = [](int m) { return NM == 8 ? m : (m * 3 + 1) / 2; };
         const uint32_t sbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) uint16_t *)smem);
         uint32_t kl[4];                                            // K fragment byte offsets inside a slot (block A; block B: + 4096)
 #pragma unroll
@@ -917,19 +919,26 @@ __global__ void __launch_bounds__(NW * 64, PIPE ? 2 : 3) k_attn32(AttnArgs a) {
             asm volatile("" : "+v"(tg[g]), "+v"(pk[g]));           // computed HERE: the IR sinks unpinned values past B1 to their first use
         };
         // O += V P of one block with the row-sum chain in the gaps (the last group's soft_f first)
-        auto pv = [&](auto neg_tag, auto &&after_second) __attribute__((always_inline)) {
+        // (single-pass score forms, NM == 4: a block has 4 score MFMAs for the same 16 exponentials, so the last two groups of a block's
+        // softmax run in the first two PV gaps -- the second half of P, pf1, is only needed by the third PV MFMA)
+        auto pv = [&](auto neg_tag, auto &&after_second, const f32x16 &sc) __attribute__((always_inline)) {
             constexpr bool NEG = decltype(neg_tag)::value;
-            soft_f(7, neg_tag);
-            uint4 u0 = make_uint4(pk[0], pk[1], pk[2], pk[3]), u1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-            const bf16x8 pf0 = *reinterpret_cast<bf16x8 *>(&u0), pf1 = *reinterpret_cast<bf16x8 *>(&u1);
+            if (NM == 8) soft_f(7, neg_tag);
+            uint4 u0 = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            const bf16x8 pf0 = *reinterpret_cast<bf16x8 *>(&u0);
             float ls = 0.f;
             o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(va[0], va[1], 0, 1, 2, 3, 4, 5, 6, 7), pf0, o[0], 0, 0, 0);
             ls += tg[0]; ls += tg[1];
+            if (NM == 4) { soft_e(sc, 6); soft_f(5, neg_tag); }
             __builtin_amdgcn_sched_barrier(0);
             o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(va[2], va[3], 0, 1, 2, 3, 4, 5, 6, 7), pf0, o[1], 0, 0, 0);
             ls += tg[2]; ls += tg[3];
+            if (NM == 4) { soft_e(sc, 7); soft_f(6, neg_tag); }
             after_second();
             __builtin_amdgcn_sched_barrier(0);
+            if (NM == 4) soft_f(7, neg_tag);
+            uint4 u1 = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            const bf16x8 pf1 = *reinterpret_cast<bf16x8 *>(&u1);
             o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_shufflevector(va[4], va[5], 0, 1, 2, 3, 4, 5, 6, 7), pf1, o[0], 0, 0, 0);
             ls += tg[4]; ls += tg[5];
             __builtin_amdgcn_sched_barrier(0);
@@ -987,8 +996,7 @@ __global__ void __launch_bounds__(NW * 64, PIPE ? 2 : 3) k_attn32(AttnArgs a) {
             for (int m = 0; m < NM; ++m) {
                 s_mfma(sc1, m);
 #pragma unroll
-                for (int gg = 0; gg < GPM; ++gg) {
-                    const int g = m * GPM + gg;
+                for (int g = slot_lo(m); g < slot_lo(m + 1); ++g) {
                     soft_e(sc0, g);
                     if (g > 0) soft_f(g - 1, std::false_type{});
                 }
@@ -1007,7 +1015,7 @@ __global__ void __launch_bounds__(NW * 64, PIPE ? 2 : 3) k_attn32(AttnArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             // P2
-            pv(std::false_type{}, [&]() __attribute__((always_inline)) { if (MORE && t + 3 < t1) dma_one(t + 3, (sl + 3) & 3, 1); });
+            pv(std::false_type{}, [&]() __attribute__((always_inline)) { if (MORE && t + 3 < t1) dma_one(t + 3, (sl + 3) & 3, 1); }, sc0);
             // P3
             if (MORE) wait_k();
             v_reads(sb, std::integral_constant<int, 1>{});         // V_B(t)
@@ -1016,8 +1024,7 @@ __global__ void __launch_bounds__(NW * 64, PIPE ? 2 : 3) k_attn32(AttnArgs a) {
             for (int m = 0; m < NM; ++m) {
                 if (MORE) s_mfma(sc0, m);
 #pragma unroll
-                for (int gg = 0; gg < GPM; ++gg) {
-                    const int g = m * GPM + gg;
+                for (int g = slot_lo(m); g < slot_lo(m + 1); ++g) {
                     soft_e(sc1, g);
                     if (g > 0) soft_f(g - 1, neg_tag);
                 }
@@ -1028,7 +1035,7 @@ __global__ void __launch_bounds__(NW * 64, PIPE ? 2 : 3) k_attn32(AttnArgs a) {
             wait_v();
             if (MORE) k_reads(sb1, std::integral_constant<int, 1>{});   // K_B(t+1)
             // P4
-            pv(neg_tag, []() __attribute__((always_inline)) {});
+            pv(neg_tag, []() __attribute__((always_inline)) {}, sc1);
         };
         int t = t0;
         if (TL == 2 && pair_mode) {                                // keys 32..63 of every tile are subtracted
@@ -1315,13 +1322,14 @@ int plan_k32_waves(int nq, int nkv, int dh, bool split) {      // split = K / V 
     }
     return 0;
 }
-// the pipelined form of k_attn32 (2 workgroups per CU) is the default for 4 waves and a split (hi + lo) query: bit-identical to the
-// other form, same-box +4-10 % on the signed stream and +2.5 % on the bench step.  With a plain or single-fp16 query a block has 4 score
-// MFMAs for the same 16 exponentials and it measured 0-5 % slower (mixed16 bench step -1 %): not used there.  LVQ_ATTN_NO_PIPE=1 / LVQ_ATTN_PIPE=1 force one form for every
+// the pipelined form of k_attn32 (2 workgroups per CU) is the default for 4 waves and a split (hi + lo) or single-fp16 query: bit-identical
+// to the other form, same-box +4-10 % on the signed stream and +2.5 % on the bench step (mixed16: +1.4 % once the last two softmax groups
+// of a block moved into the PV gaps).  With a plain bf16 query (4 score MFMAs per block for the same 16 exponentials, no second pass to
+// hide behind) the two forms measure within 2 % of each other either way and the 3-waves-per-SIMD form stays.  LVQ_ATTN_NO_PIPE=1 / LVQ_ATTN_PIPE=1 force one form for every
 // query kind (A/B: tools/ab_attn_pipe.py; DESIGN 3.2 has the measurements)
 bool k32_pipe(int nw, int qs) {
     if (nw != 4 || getenv("LVQ_ATTN_NO_PIPE") != nullptr) return false;
-    return qs == 1 || getenv("LVQ_ATTN_PIPE") != nullptr;
+    return qs != 0 || getenv("LVQ_ATTN_PIPE") != nullptr;
 }
 AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, bool allow32 = false, int qs = 0) {
     AttnPlan p;

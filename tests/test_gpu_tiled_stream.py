@@ -312,7 +312,7 @@ def test_attention_tiled_signed_falls_back_when_unusable(kind):
                                                       (1, 2, 120, 67, 0.3, True), (2, 2, 240, 72, 0.3, False)])
 def test_pipelined_stream_is_bit_identical(B, H, nq, n_tiles, fr, qsplit, monkeypatch):
     """The software-pipelined form of the long-stream kernel (4 LDS slots, loader-only waves for the query padding; the default for
-    split queries, LVQ_ATTN_PIPE=1 forces it for the other kinds) against the plain form (LVQ_ATTN_NO_PIPE=1).  Same arithmetic in
+    split and fp16 queries, LVQ_ATTN_PIPE=1 forces it for plain ones) against the plain form (LVQ_ATTN_NO_PIPE=1).  Same arithmetic in
     the same order: with the KV split pinned, the tiled stream, the per-model totals and the signed pair stream (pair lists of any
     length, full-list batches, 1 .. n tiles per split) are equal bit for bit."""
     o = ops()
