@@ -156,8 +156,11 @@ __global__ void __launch_bounds__(256) k_pillar_vfe1(const float4 *__restrict__ 
                                                      const int32_t *__restrict__ coords, int64_t m_cap,
                                                      const int32_t *__restrict__ n_live, int T, PfnParams P,
                                                      float *__restrict__ out) {
-    constexpr int FP = 12;                                   // padded feature row (floats): three 16-byte chunks
-    __shared__ __attribute__((aligned(16))) float feat[4][32][FP];
+    constexpr int FP = 12;                                   // padded feature count
+    // feature-major staging: feat[w][k][j] = feature k of point j, so one 16-byte broadcast read brings feature k of FOUR points and
+    // the products run as packed fp32 FMAs (two points per instruction, the weight broadcast by op_sel).  The kernel is bound by
+    // vector issue (64 channels x T points x cin products per pillar): ~260 -> ~160 vector instructions per pillar
+    __shared__ __attribute__((aligned(16))) float feat[4][FP][32];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int64_t m = n_live ? (int64_t)*n_live : m_cap;
     if (m > m_cap) m = m_cap;
@@ -200,40 +203,38 @@ __global__ void __launch_bounds__(256) k_pillar_vfe1(const float4 *__restrict__ 
         else         { f[1] = cl[0]; f[2] = cl[1]; f[3] = cl[2]; f[4] = ce[0]; f[5] = ce[1]; f[6] = ce[2]; if (P.flags & 2) f[7] = dist; }
         (void)q;
         const bool live = lane < np && lane < T;              // padding mask (pillar_vfe.py:117-120)
-        float4 *dst = reinterpret_cast<float4 *>(&feat[wid][lane][0]);
-        dst[0] = live ? make_float4(f[0], f[1], f[2], f[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[1] = live ? make_float4(f[4], f[5], f[6], f[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        dst[2] = live ? make_float4(f[8], f[9], f[10], f[11]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < FP; ++k) feat[wid][k][lane] = live ? f[k] : 0.f;
     }
     wave_sync();
-    // the loop is bound by its LDS broadcast reads (every lane the same 16 bytes: 4 LDS cycles each).  With <= 10 input features --
-    // the PointPillars default -- the third read of a point is 8 bytes and the two products with zero weights and zero features
-    // (exactly + 0) are not issued
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     float mx = -INFINITY;
-    if (cin <= 10) {
-#pragma unroll 4
-        for (int j = 0; j < T; ++j) {
-            const float4 *src = reinterpret_cast<const float4 *>(&feat[wid][j][0]);
-            const float4 a = src[0], b = src[1];
-            const float2 c2 = *reinterpret_cast<const float2 *>(&feat[wid][j][8]);
-            float acc = 0.f;
-            acc = fmaf(a.x, wreg[0], acc); acc = fmaf(a.y, wreg[1], acc); acc = fmaf(a.z, wreg[2], acc); acc = fmaf(a.w, wreg[3], acc);
-            acc = fmaf(b.x, wreg[4], acc); acc = fmaf(b.y, wreg[5], acc); acc = fmaf(b.z, wreg[6], acc); acc = fmaf(b.w, wreg[7], acc);
-            acc = fmaf(c2.x, wreg[8], acc); acc = fmaf(c2.y, wreg[9], acc);
-            mx = fmaxf(mx, fmaxf(acc * sc + sh, 0.f));
+    // per point: acc = sum_k f[k] * w[k] in ascending k from 0 (the order of the scalar form: bit-identical), then BN + ReLU + max
+    auto quads = [&](auto kk_tag) __attribute__((always_inline)) {
+        constexpr int KK = decltype(kk_tag)::value;
+        const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
+        for (int j0 = 0; j0 < T; j0 += 8) {                   // two quads per round: four independent accumulation chains
+            f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+            for (int k = 0; k < KK; ++k) {
+                const float4 p0 = *reinterpret_cast<const float4 *>(&feat[wid][k][j0]);
+                const float4 p1 = *reinterpret_cast<const float4 *>(&feat[wid][k][(j0 + 4) & 31]);
+                const f32x2 w2 = {wreg[k], wreg[k]};
+                acc[0] = __builtin_elementwise_fma(f32x2{p0.x, p0.y}, w2, acc[0]);
+                acc[1] = __builtin_elementwise_fma(f32x2{p0.z, p0.w}, w2, acc[1]);
+                acc[2] = __builtin_elementwise_fma(f32x2{p1.x, p1.y}, w2, acc[2]);
+                acc[3] = __builtin_elementwise_fma(f32x2{p1.z, p1.w}, w2, acc[3]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x2 y = acc[q] * sc2 + sh2;               // (mul, then add: -ffp-contract=off, as the scalar form)
+                if (j0 + 2 * q < T) mx = fmaxf(mx, fmaxf(y[0], 0.f));
+                if (j0 + 2 * q + 1 < T) mx = fmaxf(mx, fmaxf(y[1], 0.f));
+            }
         }
-    } else {
-#pragma unroll 4
-        for (int j = 0; j < T; ++j) {
-            const float4 *src = reinterpret_cast<const float4 *>(&feat[wid][j][0]);
-            const float4 a = src[0], b = src[1], c4 = src[2];
-            float acc = 0.f;
-            acc = fmaf(a.x, wreg[0], acc); acc = fmaf(a.y, wreg[1], acc); acc = fmaf(a.z, wreg[2], acc); acc = fmaf(a.w, wreg[3], acc);
-            acc = fmaf(b.x, wreg[4], acc); acc = fmaf(b.y, wreg[5], acc); acc = fmaf(b.z, wreg[6], acc); acc = fmaf(b.w, wreg[7], acc);
-            acc = fmaf(c4.x, wreg[8], acc); acc = fmaf(c4.y, wreg[9], acc); acc = fmaf(c4.z, wreg[10], acc); acc = fmaf(c4.w, wreg[11], acc);
-            mx = fmaxf(mx, fmaxf(acc * sc + sh, 0.f));
-        }
-    }
+    };
+    if (cin <= 10) quads(std::integral_constant<int, 10>{});
+    else           quads(std::integral_constant<int, 12>{});
     if (act) out[v * cout + lane] = mx;
 }
 
