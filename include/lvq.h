@@ -317,6 +317,29 @@ int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *
                        int64_t v_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, int causal,
                        lvq_bf16 *o, lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream);
 
+/* ---- Fused short-K/V cross-attention sub-path (csrc/cross_fused.hip) -------------------------------------------------------
+ * out = q + ca(ca_ln(q), kv, kv): encoder-decoder/training/models/vat_blocks.py:41-42 (nn.LayerNorm + nn.MultiheadAttention with
+ * batch_first, eval mode) as TWO launches: the K|V projection of the kv tokens (written straight in MFMA fragment order into `ws`)
+ * and one kernel that takes the fp32 queries through LayerNorm, the Q projection, softmax(Q K^T / sqrt(dh)) V, the out projection,
+ * bias and the fp32 residual without an activation round trip through HBM.  BASELINE.json's metric shape is
+ * (batch, nq, nkv, d, n_heads) = (1, 32768, 196, 768, 12).
+ *   lvq_ca_fused_ok       1 for the shapes the kernel family takes: d = 768, n_heads = 12 (head_dim 64), nq % 32 == 0, 1 <= nkv <= 224.
+ *   lvq_ca_fused_pack     once per weights version: ln_gamma / ln_beta [d] (ca_ln), in_proj_w [3d, d], in_proj_b [3d], out_w [d, d],
+ *                         out_b [d] (ca.in_proj_weight / in_proj_bias / out_proj.*) -> `packed` (lvq_ca_fused_packed_bytes): MFMA-fragment-
+ *                         major 16-bit copies (gamma folded into W_q, beta and 1/sqrt(dh) into its bias).  f16 = 0: bf16 operands;
+ *                         f16 = 1: IEEE fp16 operands (same MFMA rate, 8x smaller operand rounding: the form that meets the 1e-3 parity
+ *                         bar, tools/precision_study_ca.py; values that are not bounded by construction are clamped to +-65504).
+ *                         A blob packed with one f16 value must be used with the same value.
+ *   lvq_ca_fused          q [batch, nq, d] fp32, kv [batch, nkv, d] fp32 -> out [batch, nq, d] fp32 (out may not alias q).
+ * All pointers are device pointers; stream-ordered; `ws` (lvq_ca_fused_workspace_bytes) is scratch for the packed K | V^T. */
+int lvq_ca_fused_ok(int batch, int nq, int nkv, int d, int n_heads);
+size_t lvq_ca_fused_packed_bytes(int d, int n_heads);
+size_t lvq_ca_fused_workspace_bytes(int batch, int nq, int nkv, int d, int n_heads);
+int lvq_ca_fused_pack(const float *ln_gamma, const float *ln_beta, const float *in_proj_w, const float *in_proj_b, const float *out_w,
+                      const float *out_b, int d, int n_heads, int f16, void *packed, size_t packed_bytes, lvq_stream_t stream);
+int lvq_ca_fused(const float *q, const float *kv, const void *packed, float eps, int batch, int nq, int nkv, int d, int n_heads, int f16,
+                 float *out, void *ws, size_t ws_bytes, lvq_stream_t stream);
+
 /* VATLiDAR front (vat_lidar.py:82-85,212): depthwise Conv2d(C,C,3,pad=1,groups=C) + exact GELU on
  * NCHW fp32 input, written TOKEN-MAJOR [B, H*W, C] as bf16 (the A operand of the 1x1-conv GEMM). */
 int lvq_dwconv3x3_gelu(const float *bev, const float *w9, const float *bias, int batch, int ch, int h, int w,

@@ -51,7 +51,7 @@ def lib() -> ctypes.CDLL:
                      "lvq_sparse_bev_merge_workspace_bytes", "lvq_sparse_to_dense_workspace_bytes", "lvq_qwen2_decode_workspace_bytes",
                      "lvq_bev_tiles_workspace_bytes", "lvq_attention_workspace_bytes", "lvq_colsum_workspace_bytes",
                      "lvq_attention_stream_totals_workspace_bytes", "lvq_attention_tiled_signed_workspace_bytes",
-                     "lvq_bev_tile_kv_workspace_bytes"):
+                     "lvq_bev_tile_kv_workspace_bytes", "lvq_ca_fused_packed_bytes", "lvq_ca_fused_workspace_bytes"):
             getattr(L, name).restype = ctypes.c_size_t
         _lib = L
     return _lib

@@ -1,0 +1,727 @@
+// csrc/cross_fused.hip -- the short-K/V cross-attention sub-path of VATBlock as ONE kernel (gfx950):
+//
+//     out = q + ca(ca_ln(q), kv, kv)            encoder-decoder/training/models/vat_blocks.py:41-42
+//
+// at the shapes BASELINE.json's metric names: (B, Nq, Nkv, d, h) = (1, 32768, 196, 768, 12) "32k pts x 196 patches", and the
+// resampled-token forms (B, 576, 196), i.e. many queries against a few hundred keys.  The unfused sequence (LayerNorm, Q projection,
+// K|V projection, attention, out projection + residual: five launches) moves 24-36 B per activation element through HBM for a problem
+// whose algorithmic traffic is 8 B (fp32 q in, fp32 out); here the activation never leaves the CU between the fp32 load and the fp32 store.
+//
+// Structure.  A workgroup = 4 waves, one per SIMD, each with the whole 512-register file; a wave owns 32 query rows and keeps, as MFMA
+// operand fragments IN REGISTERS: LayerNorm(x) of its rows (192 registers), then Q of all heads (192), overwritten head by head with the
+// attention output O.  Every product is computed TRANSPOSED (C^T = W . X^T): the query sits on the lane, so
+//   * LayerNorm is two lanes per row and one permlane swap,
+//   * the Q^T accumulator tile IS the B operand of S^T = K Q^T, the exponentiated S^T IS the B operand of O^T = V^T P^T and O^T IS
+//     the B operand of out^T = W_o O^T (MI355X guide: "an accumulator tile as the next MFMA's operand") -- nothing is ever shuffled
+//     between lanes or staged through LDS, and softmax statistics are per-lane scalars + one permlane swap.
+// All A operands (W_q, K, V^T, W_o) are PRE-PACKED in MFMA fragment order (1 KiB = one wave-instruction per 32 x 16 fragment, with the
+// k permutation pi(ks, half, j) = 16 ks + 8 (j >> 2) + 4 half + (j & 3) that the accumulator-as-operand identity imposes) and arrive as
+// ONE linear fragment stream per workgroup through an LDS ring filled by LDS-DMA (global_load_lds, 16 B per lane): the four waves share
+// every fragment, so the stream leaves L2 once per 128 rows (3 MB per workgroup; 0.8 GB per call at the headline shape).  The fp32
+// residual rows come back the same way (LDS-DMA with a per-lane gather address into a wave-private LDS area), so the steady state issues
+// no register-destination global load at all and every wait in the stream is a counted vmcnt / lgkmcnt placed by hand.
+// The K|V projection of the few hundred kv tokens is a small kernel of its own that writes K and V^T directly in fragment order.
+//
+// Operand type: bf16 or IEEE fp16 (same MFMA rate).  tools/precision_study_ca.py: with every operand rounded once to fp16 the sub-path
+// is 4.3e-4 from the fp64 result at the headline shape (bf16: 3.6e-3; tolerance 1e-3), so the fp16 form is the parity-true one.
+// fp16's range is guarded where a value is not bounded by construction (kv tokens, K, V, scaled Q: clamped to +-65504).
+#include "common.h"
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef short h16x8 __attribute__((ext_vector_type(8)));       // eight 16-bit MFMA operands (bf16 or fp16 bit patterns)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int D = 768, NH = 12, DH = 64;
+constexpr int NKS = D / 16;                 // 48 k-steps of a 768-deep product
+constexpr int FRAG = 1024;                  // bytes of one fragment = one wave-instruction of 16 B per lane
+constexpr int GROUP = 16;                   // fragments per ring group (one barrier per group)
+constexpr int NSLOT = 4;                    // ring slots
+constexpr int NW = 4;                       // waves per workgroup
+constexpr int DPG = GROUP / NW;             // LDS-DMA instructions per wave and group
+constexpr int RING_BYTES = NSLOT * GROUP * FRAG;         // 64 KiB
+constexpr int QL = 5;                       // heads whose Q / O fragments wait in LDS during phases A and B
+constexpr int RESID_BYTES = (4 * QL > GROUP ? 4 * QL : GROUP) * FRAG;   // per wave: parked Q / O fragments, then (phase C) 32 rows x 128 columns fp32
+constexpr int TAB_OFF = RING_BYTES + NW * RESID_BYTES;   // three [768] fp32 tables: bias' of Q, row sums of W_q', b_o
+constexpr int LDS_BYTES = TAB_OFF + 3 * D * 4;
+constexpr int NBC = 4;                      // 32-column blocks per out-projection chunk (128 columns)
+constexpr int NCHUNK = D / (32 * NBC);      // 6
+
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+template <bool F16> __device__ __forceinline__ f32x16 mfma(const h16x8 &a, const h16x8 &b, const f32x16 &c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// two fp32 -> one packed pair, round to nearest even (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32)
+template <bool F16> __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    if constexpr (F16) {
+        f16x2_t p = {(_Float16)a, (_Float16)b};
+        return __builtin_bit_cast(uint32_t, p);
+    } else {
+        bf16x2_t p = {(__bf16)a, (__bf16)b};
+        return __builtin_bit_cast(uint32_t, p);
+    }
+}
+__device__ __forceinline__ float clamp16(float x) { return __builtin_fminf(__builtin_fmaxf(x, -65504.f), 65504.f); }
+template <bool F16, bool CLAMP = false> __device__ __forceinline__ h16x8 pack8(const float (&v)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float a = v[2 * i], b = v[2 * i + 1];
+        if (F16 && CLAMP) a = clamp16(a), b = clamp16(b);
+        w[i] = pack2<F16>(a, b);
+    }
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 u = {w[0], w[1], w[2], w[3]};
+    return __builtin_bit_cast(h16x8, u);
+}
+
+// LDS reads as opaque asm (the compiler's waitcnt pass would put vmcnt(0) in front of any LDS read it can see while an LDS-DMA is in
+// flight, i.e. drain the ring); the consumer waits on lgkmcnt itself (hardware returns LDS data in order)
+template <int OFF> __device__ __forceinline__ void lds_read(h16x8 &d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void lds_read(f32x4 &d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_wait0(h16x8 (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])::"memory");
+}
+__device__ __forceinline__ void lds_wait4(h16x8 (&f)[4]) {      // leaves the four newest reads (the next batch) in flight
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])::"memory");
+}
+__device__ __forceinline__ void lds_wait0(f32x4 (&f)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7])::"memory");
+}
+// pins a value where it is computed: LLVM otherwise sinks pure arithmetic to its first use (for Q / O fragments: a whole phase later,
+// with the accumulators and table values it depends on kept alive -- i.e. spilled -- until then)
+__device__ __forceinline__ void pin(h16x8 &x) { asm volatile("" : "+v"(x)); }
+template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__device__ __forceinline__ float swap_sum(float x) {            // x(lane) + x(lane ^ 32)
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap_max(float x) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+struct CaArgs {
+    const float *x;          // [rows, D] fp32: the queries (= the residual stream)
+    float *out;              // [rows, D] fp32
+    const char *wq;          // packed W_q' fragments [head][ks][dh block]      (gamma folded in)
+    const char *wo;          // packed W_o fragments [chunk][ks][column block]
+    const char *kv;          // packed K / V^T fragments [batch][head][CF]
+    const float *tabs;       // [3][D] fp32: (b_q + W_q beta) * qscale | row sums of the rounded W_q' | b_o
+    int nq, nkv;             // rows per batch element, keys
+    int tiles_per_batch;     // ceil(nq / 128)
+    int64_t kv_batch_bytes;
+    float eps, qscale;       // qscale = log2(e) / sqrt(dh)
+};
+
+template <int OFF> __device__ __forceinline__ void lds_write(uint32_t addr, const h16x8 &d) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(d), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_wait0_4(h16x8 &a, h16x8 &b, h16x8 &c, h16x8 &d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+__device__ __forceinline__ void lds_wait0(f32x4 (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])::"memory");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The fused kernel.  KC = 32-key blocks of the K|V stream (all scores of a row live in registers, one softmax pass; nkv <= 32 KC).
+// Fragment stream of one workgroup (groups of 16 fragments; every consumer step is a "batch" of 4 fragments = 4 MFMAs per wave):
+//   A  12 heads x [48 k-steps x 2 dh-blocks] of W_q'            72 groups
+//   B  12 heads x [K: KC x 4 | V^T: KC x 4 | pad]               12 x CG groups
+//   C   6 chunks x [48 k-steps x 4 column blocks] of W_o        72 groups
+// Registers (512 per lane, one wave per SIMD): the row's 16-bit operand fragments xd (192, phase A), Q / O of heads QL..11 (128;
+// heads 0..QL-1 live in this wave's residual area in LDS until phase C has room for them), scores (112) and P (56) of one head.
+// ---------------------------------------------------------------------------------------------------------------------------------
+
+template <bool F16, int KC>
+__global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
+    constexpr int CF = (8 * KC + GROUP - 1) / GROUP * GROUP;    // fragments per (batch, head) of the K|V stream
+    constexpr int CG = CF / GROUP;
+    constexpr int GA = NH * 6, GB = NH * CG, GC = NCHUNK * 12, GTOT = GA + GB + GC;
+    constexpr int NBT = GTOT * 4;                               // batches
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q31 = lane & 31, h2 = lane >> 5;
+    const int batch = blockIdx.x / a.tiles_per_batch, tile = blockIdx.x % a.tiles_per_batch;
+    const int r0 = tile * (NW * 32) + wid * 32;                 // first row of this wave inside its batch element
+    const bool active = r0 < a.nq;                              // nq % 32 == 0: a wave is whole or absent (absent waves still load and sync)
+    const int64_t row = (int64_t)batch * a.nq + (active ? r0 + q31 : q31);
+    const uint32_t sbase = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char *)smem);
+    const uint32_t fr_addr = sbase + lane * 16;                                      // ring: + slot * 16 KiB + fragment * 1 KiB (immediates)
+    const uint32_t rs_addr = sbase + RING_BYTES + wid * RESID_BYTES + lane * 16;     // this wave's residual rows / parked Q, O fragments
+    const uint32_t tb_addr = sbase + TAB_OFF + h2 * 16;                              // tables: + table * 3 KiB + column * 4
+    const uint32_t voff = (uint32_t)(wid * FRAG + lane * 16);                        // this lane's bytes of this wave's fragments
+    const char *segA = a.wq, *segC = a.wo, *segB = a.kv + (int64_t)batch * a.kv_batch_bytes;
+
+    // ---- per-column tables -> LDS (before any LDS-DMA is in flight: plain stores) ----
+    {
+        float *tab = reinterpret_cast<float *>(smem + TAB_OFF);
+        for (int i = tid; i < 3 * D; i += NW * 64) tab[i] = a.tabs[i];
+    }
+    __syncthreads();
+
+    // piece j (0 .. DPG - 1) of this wave's share of ring group G: fragment NW j + wid
+    auto issue_piece = [&](auto gi, auto ji) __attribute__((always_inline)) {
+        constexpr int G = decltype(gi)::value, j = decltype(ji)::value;
+        const char *seg = G < GA ? segA : (G < GA + GB ? segB : segC);
+        constexpr int GL = G < GA ? G : (G < GA + GB ? G - GA : G - GA - GB);
+        const char *src = seg + ((int64_t)GL * GROUP + NW * j) * FRAG + voff;
+        char *dst = smem + (G % NSLOT) * (GROUP * FRAG) + (NW * j) * FRAG + wid * FRAG;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    auto issue_group = [&](auto gi) __attribute__((always_inline)) {
+        static_for<0, DPG>([&](auto j) { issue_piece(gi, j); });
+    };
+    static_for<0, NSLOT>([&](auto g) { issue_group(g); });       // the ring starts full: groups 0 .. NSLOT - 1
+
+    // ---- LayerNorm, streaming: two lanes per row, one pass over the row, straight into B-operand fragments ----
+    // lane (q, h2) holds x[q][16 ks + 8 (j >> 2) + 4 h2 + (j & 3)], j = 0..7, of every k-step (half a row).  The fragments carry
+    // d = x - c rounded to 16 bits, c = the mean of the row's first 64 elements (so |d| is a few standard deviations whatever the
+    // row's offset); the exact statistics of d (fp32) turn the product into LayerNorm in the Q epilogue:
+    //   W' ((d - mu_d) rstd) = rstd (W' d) - (mu_d rstd) rowsum(W')          (gamma is folded into W', beta into the bias)
+    h16x8 xd[NKS];
+    float q_a, q_b;                            // rstd * qscale, mu_d * rstd * qscale
+    {
+        const float *xr = a.x + row * D + 4 * h2;
+        constexpr int CH = 4;                  // k-steps per load chunk (8 float4 per lane)
+        f32x4 first[2 * CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            first[2 * i] = *reinterpret_cast<const f32x4 *>(xr + 16 * i);
+            first[2 * i + 1] = *reinterpret_cast<const f32x4 *>(xr + 16 * i + 8);
+        }
+        float c0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2 * CH; ++i) c0 += (first[i][0] + first[i][1]) + (first[i][2] + first[i][3]);
+        const float cshift = swap_sum(c0) * (1.0f / (16 * CH));
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NKS / CH; ++c) {
+            f32x4 raw[2 * CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (c == 0) {
+                    raw[2 * i] = first[2 * i], raw[2 * i + 1] = first[2 * i + 1];
+                } else {
+                    raw[2 * i] = *reinterpret_cast<const f32x4 *>(xr + 16 * (CH * c + i));
+                    raw[2 * i + 1] = *reinterpret_cast<const f32x4 *>(xr + 16 * (CH * c + i) + 8);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                float e[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) e[j] = raw[2 * i][j] - cshift, e[4 + j] = raw[2 * i + 1][j] - cshift;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s1 += e[j], s2 += e[j] * e[j];
+                xd[CH * c + i] = pack8<F16, true>(e);
+                pin(xd[CH * c + i]);
+            }
+        }
+        const float mu = swap_sum(s1) * (1.0f / D);
+        const float var = __builtin_fmaxf(swap_sum(s2) * (1.0f / D) - mu * mu, 0.f);
+        const float rstd = 1.0f / sqrtf(var + a.eps);
+        q_a = rstd * a.qscale;
+        q_b = mu * q_a;
+    }
+
+    // ---- the stream ----
+    h16x8 FA[4], FB[4];                       // two batches of fragments (the next batch is read while the current one feeds MFMAs)
+    h16x8 qf[NKS];                            // Q^T as B fragments, then O^T (same slots); slots of heads < QL are filled at the start of phase C
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    auto read4 = [&](auto bi, h16x8(&f)[4]) __attribute__((always_inline)) {
+        constexpr int GBI = decltype(bi)::value, G = GBI / 4, B4 = GBI % 4;
+        constexpr int base = (G % NSLOT) * (GROUP * FRAG) + B4 * 4 * FRAG;
+        lds_read<base>(f[0], fr_addr);
+        lds_read<base + FRAG>(f[1], fr_addr);
+        lds_read<base + 2 * FRAG>(f[2], fr_addr);
+        lds_read<base + 3 * FRAG>(f[3], fr_addr);
+    };
+    // the residual rows of out-projection chunk c, fragment u = 4 nb + g: for lane (q, h2), x[q][128 c + 32 nb + 8 g + 4 h2 .. + 3] --
+    // exactly the epilogue's operand, in the lane that needs it
+    auto issue_resid = [&](auto ci, auto ui) __attribute__((always_inline)) {
+        constexpr int c = decltype(ci)::value, u = decltype(ui)::value, nb = u >> 2, g = u & 3;
+        const float *src = a.x + row * D + 128 * c + 32 * nb + 8 * g + 4 * h2;
+        char *dst = smem + RING_BYTES + wid * RESID_BYTES + u * FRAG;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+    // end of ring group G (this wave has received every fragment of G it reads): group G + 1 has landed for everyone after the
+    // barrier, and the slot of G is free for group G + NSLOT, whose pieces go out one per batch from here on (`mid` below)
+    auto advance = [&](auto gi) __attribute__((always_inline)) {
+        constexpr int G = decltype(gi)::value;
+        constexpr int after = GTOT - 2 - G;                                      // groups behind G + 1
+        constexpr int inflight = after < 0 ? 0 : (after < NSLOT - 2 ? after : NSLOT - 2);
+        vm_wait<DPG * inflight>();
+        __builtin_amdgcn_s_barrier();
+    };
+    // one consumer step: batch GBI of the stream.  The body issues its four MFMAs and calls mid(0), mid(1), mid(2) between them: the
+    // requests that keep the stream going ride in the MFMAs' shadows (an MFMA holds the issue port 8 of its 32 cycles) --
+    //   mid(0), mid(1)  the next batch's four fragment reads
+    //   mid(2)          one LDS-DMA piece of ring group G + NSLOT - 1 (its slot was freed by the barrier at the end of group G - 1) and,
+    //                   in phase C, one piece of the chunk's residual rows
+    // LATE: the body carries compiler-scheduled vector code (an epilogue, the softmax) -- the next batch is then requested AFTER the
+    // body: a register that an in-flight asm ds_read is about to fill looks defined to the register allocator, which under pressure
+    // may copy or spill it before the data is there (tools/check_asm_hazards.py)
+    auto step_impl = [&](auto bi, auto late, h16x8(&cur)[4], h16x8(&nxt)[4], auto &&body) __attribute__((always_inline)) {
+        constexpr int GBI = decltype(bi)::value, G = GBI / 4, B4 = GBI % 4;
+        constexpr bool has_next = GBI + 1 < NBT, LATE = decltype(late)::value;
+        lds_wait0(cur);
+        if constexpr (B4 == 3 && has_next) advance(std::integral_constant<int, G>{});
+        __builtin_amdgcn_sched_barrier(0);
+        auto mid = [&](auto mi) __attribute__((always_inline)) {
+            constexpr int m = decltype(mi)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (m < 2 && has_next && !LATE) {
+                constexpr int G1 = (GBI + 1) / 4, base = (G1 % NSLOT) * (GROUP * FRAG) + ((GBI + 1) % 4) * 4 * FRAG + 2 * m * FRAG;
+                lds_read<base>(nxt[2 * m], fr_addr);
+                lds_read<base + FRAG>(nxt[2 * m + 1], fr_addr);
+            }
+            if constexpr (m == 2) {
+                constexpr int t = GBI - 3;                                       // piece t % 4 of group t / 4 + NSLOT
+                if constexpr (t >= 0 && t / 4 + NSLOT < GTOT) issue_piece(std::integral_constant<int, t / 4 + NSLOT>{}, std::integral_constant<int, t % 4>{});
+                if constexpr (GBI >= (GA + GB) * 4) {                            // residual rows of chunk c: 16 pieces over its batches 4 .. 19
+                    constexpr int bc = GBI - (GA + GB) * 4, c = bc / NKS, u = bc % NKS - 4;
+                    if constexpr (u >= 0 && u < 16) issue_resid(std::integral_constant<int, c>{}, std::integral_constant<int, u>{});
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        body(cur, mid);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (has_next && LATE) read4(std::integral_constant<int, GBI + 1>{}, nxt);
+    };
+    auto step = [&](auto bi, auto late, auto &&body) __attribute__((always_inline)) {
+        constexpr int GBI = decltype(bi)::value;
+        if constexpr (GBI % 2 == 0) step_impl(bi, late, FA, FB, body);
+        else step_impl(bi, late, FB, FA, body);
+    };
+    const std::integral_constant<int, 0> M0{};
+    const std::integral_constant<int, 1> M1{};
+    const std::integral_constant<int, 2> M2{};
+
+    // group 0 has landed (this wave's pieces: counted; everyone's: barrier); first batch
+    vm_wait<DPG *(NSLOT - 1)>();
+    __builtin_amdgcn_s_barrier();
+    read4(std::integral_constant<int, 0>{}, FA);
+
+    // ================================ A: Q^T = W_q' LN(x)^T, head by head ================================
+    static_for<0, NH>([&](auto hi) {
+        constexpr int h = decltype(hi)::value;
+        f32x16 acc0, acc1;
+        static_for<0, 24>([&](auto li) {
+            constexpr int lb = decltype(li)::value, ks = 2 * lb;
+            step(std::integral_constant<int, (h * 6) * 4 + lb>{}, std::integral_constant<bool, lb == 23>{}, [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
+                if constexpr (lb == 0) acc0 = mfma<F16>(f[0], xd[ks], zero);
+                else acc0 = mfma<F16>(f[0], xd[ks], acc0);
+                mid(M0);
+                if constexpr (lb == 0) acc1 = mfma<F16>(f[1], xd[ks], zero);
+                else acc1 = mfma<F16>(f[1], xd[ks], acc1);
+                mid(M1);
+                acc0 = mfma<F16>(f[2], xd[ks + 1], acc0);
+                mid(M2);
+                acc1 = mfma<F16>(f[3], xd[ks + 1], acc1);
+                if constexpr (lb == 23) {
+                    // Q^T (scaled by log2(e) / sqrt(dh)) = acc * q_a - rowsum(W') * q_b + bias' -> B fragments of S^T = K Q^T;
+                    // row (= dh) of register r of block blk: 32 blk + (r & 3) + 8 (r >> 2) + 4 h2
+                    static_for<0, 4>([&](auto ui) {
+                        constexpr int blk = decltype(ui)::value >> 1, sx = decltype(ui)::value & 1;
+                        f32x4 t[4];                               // t[0..1] bias', t[2..3] row sums: rows 64 h + 32 blk + 16 sx + 8 g + 4 h2 .. + 3
+                        lds_read<(64 * h + 32 * blk + 16 * sx) * 4>(t[0], tb_addr);
+                        lds_read<(64 * h + 32 * blk + 16 * sx + 8) * 4>(t[1], tb_addr);
+                        lds_read<(D + 64 * h + 32 * blk + 16 * sx) * 4>(t[2], tb_addr);
+                        lds_read<(D + 64 * h + 32 * blk + 16 * sx + 8) * 4>(t[3], tb_addr);
+                        lds_wait0(t);
+                        const f32x16 &acc = blk ? acc1 : acc0;
+                        float e[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) e[j] = acc[8 * sx + j] * q_a + (t[j >> 2][j & 3] - t[2 + (j >> 2)][j & 3] * q_b);
+                        const h16x8 fr = pack8<F16, true>(e);
+                        if constexpr (h < QL) lds_write<(4 * h + 2 * blk + sx) * FRAG>(rs_addr, fr);
+                        else {
+                            qf[4 * h + 2 * blk + sx] = fr;
+                            pin(qf[4 * h + 2 * blk + sx]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);        // keep the four units apart (their table reads would otherwise be hoisted together)
+                    });
+                }
+            });
+        });
+    });
+
+    // ================================ B: attention, head by head ================================
+    static_for<0, NH>([&](auto hi) {
+        constexpr int h = decltype(hi)::value;
+        constexpr int GB0 = (GA + h * CG) * 4;                 // first batch of this head
+        f32x16 sacc[KC];
+        h16x8 pf[KC][2];
+        h16x8 qh[4];                                            // this head's Q^T fragments
+        f32x16 o0, o1;
+        float linv = 0.f;
+        if constexpr (h < QL) {                                 // parked Q: back from LDS (no vector code between the reads and their wait)
+            static_for<0, 4>([&](auto si) { lds_read<(4 * h + decltype(si)::value) * FRAG>(qh[decltype(si)::value], rs_addr); });
+            lds_wait0(qh);                                      // (also retires the first batch's reads, requested just before: harmless)
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qh[i] = qf[4 * h + i];
+        }
+        static_for<0, 4 * CG>([&](auto li) {
+            constexpr int lb = decltype(li)::value;
+            step(std::integral_constant<int, GB0 + lb>{}, std::integral_constant<bool, lb == KC - 1 || lb == 2 * KC - 1>{}, [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
+                if constexpr (lb < KC) {                        // S^T block lb = K rows 32 lb .. + 31 against Q^T (4 k-steps over dh)
+                    sacc[lb] = mfma<F16>(f[0], qh[0], zero);
+                    mid(M0);
+                    sacc[lb] = mfma<F16>(f[1], qh[1], sacc[lb]);
+                    mid(M1);
+                    sacc[lb] = mfma<F16>(f[2], qh[2], sacc[lb]);
+                    mid(M2);
+                    sacc[lb] = mfma<F16>(f[3], qh[3], sacc[lb]);
+                    if constexpr (lb == KC - 1) {               // softmax over the row's keys: 16 KC scores in this lane + as many in lane ^ 32
+#pragma unroll
+                        for (int kb = 0; kb < KC; ++kb) {
+                            if (32 * (kb + 1) > a.nkv) {        // (wave-uniform) block with keys past nkv
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h2;
+                                    sacc[kb][r] = key < a.nkv ? sacc[kb][r] : -INFINITY;
+                                }
+                            }
+                        }
+                        float m = -INFINITY;
+#pragma unroll
+                        for (int kb = 0; kb < KC; ++kb)
+#pragma unroll
+                            for (int r = 0; r < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, sacc[kb][r]), sacc[kb][r + 1]);
+                        m = swap_max(m);
+                        float l0 = 0.f, l1 = 0.f;
+#pragma unroll
+                        for (int kb = 0; kb < KC; ++kb) {
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) {
+                                float e[8];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(sacc[kb][8 * t + j] - m);
+                                l0 += (e[0] + e[1]) + (e[2] + e[3]);
+                                l1 += (e[4] + e[5]) + (e[6] + e[7]);
+                                pf[kb][t] = pack8<F16>(e);
+                                pin(pf[kb][t]);
+                            }
+                        }
+                        linv = 1.0f / swap_sum(l0 + l1);
+                    }
+                } else if constexpr (lb < 2 * KC) {             // O^T += V^T P^T over key block kb (2 k-steps x 2 dh-blocks)
+                    constexpr int kb = lb - KC;
+                    if constexpr (kb == 0) o0 = mfma<F16>(f[0], pf[kb][0], zero);
+                    else o0 = mfma<F16>(f[0], pf[kb][0], o0);
+                    mid(M0);
+                    if constexpr (kb == 0) o1 = mfma<F16>(f[1], pf[kb][0], zero);
+                    else o1 = mfma<F16>(f[1], pf[kb][0], o1);
+                    mid(M1);
+                    o0 = mfma<F16>(f[2], pf[kb][1], o0);
+                    mid(M2);
+                    o1 = mfma<F16>(f[3], pf[kb][1], o1);
+                    if constexpr (kb == KC - 1) {               // normalise -> B fragments of out^T = W_o O^T, into the slots of this head's Q
+#pragma unroll
+                        for (int blk = 0; blk < 2; ++blk) {
+                            const f32x16 &o = blk ? o1 : o0;
+#pragma unroll
+                            for (int sx = 0; sx < 2; ++sx) {
+                                float e[8];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) e[j] = o[8 * sx + j] * linv;
+                                const h16x8 fr = pack8<F16>(e);
+                                if constexpr (h < QL) {
+                                    if (blk == 0 && sx == 0) lds_write<(4 * h + 0) * FRAG>(rs_addr, fr);
+                                    else if (blk == 0) lds_write<(4 * h + 1) * FRAG>(rs_addr, fr);
+                                    else if (sx == 0) lds_write<(4 * h + 2) * FRAG>(rs_addr, fr);
+                                    else lds_write<(4 * h + 3) * FRAG>(rs_addr, fr);
+                                } else {
+                                    qf[4 * h + 2 * blk + sx] = fr;
+                                    pin(qf[4 * h + 2 * blk + sx]);
+                                }
+                            }
+                        }
+                    }
+                }
+                else {                                          // lb >= 2 KC: padding of the (batch, head) segment to whole groups
+                    mid(M0);
+                    mid(M1);
+                    mid(M2);
+                }
+            });
+        });
+    });
+
+    // ================================ C: out^T = W_o O^T in chunks of 128 columns, + b_o + residual ================================
+    // the parked O fragments of heads < QL come back first (their LDS area is about to receive the residual rows)
+    static_for<0, 4 * QL>([&](auto fi) { lds_read<decltype(fi)::value * FRAG>(qf[decltype(fi)::value], rs_addr); });
+#pragma unroll
+    for (int h = 0; h < QL; ++h) lds_wait0_4(qf[4 * h], qf[4 * h + 1], qf[4 * h + 2], qf[4 * h + 3]);
+    float *orow = a.out + row * D + 4 * h2;
+    static_for<0, NCHUNK>([&](auto ci) {
+        constexpr int c = decltype(ci)::value;
+        constexpr int GB0 = (GA + GB + c * 12) * 4;
+        f32x16 acc[NBC];
+        static_for<0, NKS>([&](auto ki) {
+            constexpr int ks = decltype(ki)::value;
+            step(std::integral_constant<int, GB0 + ks>{}, std::integral_constant<bool, ks == NKS - 1>{}, [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
+                static_for<0, NBC>([&](auto ni) {
+                    constexpr int nb = decltype(ni)::value;
+                    if constexpr (ks == 0) acc[nb] = mfma<F16>(f[nb], qf[ks], zero);
+                    else acc[nb] = mfma<F16>(f[nb], qf[ks], acc[nb]);
+                    if constexpr (nb < 3) mid(std::integral_constant<int, nb>{});
+                });
+                if constexpr (ks == NKS - 1) {
+        // epilogue: the residual pieces were requested >= 8 group ends ago, every ring wait since then covered them (vmcnt is in order)
+        static_for<0, NBC>([&](auto ni) {
+            constexpr int nb = decltype(ni)::value;
+            f32x4 t[8];                                      // t[g] residual, t[4 + g] bias, g = 0..3: columns 128 c + 32 nb + 8 g + 4 h2 .. + 3
+            static_for<0, 4>([&](auto gi) {
+                constexpr int g = decltype(gi)::value;
+                lds_read<(4 * nb + g) * FRAG>(t[g], rs_addr);
+                lds_read<(2 * D + 128 * c + 32 * nb + 8 * g) * 4>(t[4 + g], tb_addr);
+            });
+            lds_wait0(t);
+            if (active) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (acc[nb][4 * g + i] + t[4 + g][i]) + t[g][i];
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(orow + 128 * c + 32 * nb + 8 * g));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+                }
+            });
+        });
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K|V projection of the kv tokens straight into fragment order.  One workgroup per (key block, head, batch): K^T block = W_k kv^T
+// (accumulator = the K fragment of the fused kernel's S^T = K Q^T: registers 8 s .. 8 s + 7 of dh-block b are fragment 2 b + s) and
+// V block = kv W_v^T (registers 8 t .. 8 t + 7 of dh-block b are the V^T fragment (t, b)).  4 waves split the 48 k-steps, sums via LDS.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct KvArgs {
+    const float *kv;        // [B, nkv, D] fp32
+    const char *wk, *wv;    // packed [ks][24 row blocks] fragments
+    const float *bk, *bv;   // [D]
+    char *out;              // [B][NH][CF] fragments
+    int nkv, kc, cf;
+};
+
+template <bool F16> __global__ void __launch_bounds__(256) k_ca_kvproj(KvArgs a) {
+    __shared__ float red[4][4][16][64];                      // [wave][block][register][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r31 = lane & 31, h2 = lane >> 5;
+    const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int key = 32 * kb + r31;
+    const bool valid = key < a.nkv;
+    const float *kr = a.kv + ((int64_t)b * a.nkv + (valid ? key : 0)) * D + 4 * h2;
+    const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    f32x16 kt0 = zero, kt1 = zero, v0 = zero, v1 = zero;
+#pragma unroll 4
+    for (int i = 0; i < NKS / 4; ++i) {
+        const int ks = wid + 4 * i;
+        f32x4 x0 = *reinterpret_cast<const f32x4 *>(kr + 16 * ks), x1 = *reinterpret_cast<const f32x4 *>(kr + 16 * ks + 8);
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = valid ? x0[j] : 0.f, e[4 + j] = valid ? x1[j] : 0.f;
+        const h16x8 fkv = pack8<F16, true>(e);
+        const int64_t fo = ((int64_t)(ks * 24 + 2 * h) * 64 + lane) * 16;
+        const h16x8 wk0 = *reinterpret_cast<const h16x8 *>(a.wk + fo), wk1 = *reinterpret_cast<const h16x8 *>(a.wk + fo + FRAG);
+        const h16x8 wv0 = *reinterpret_cast<const h16x8 *>(a.wv + fo), wv1 = *reinterpret_cast<const h16x8 *>(a.wv + fo + FRAG);
+        kt0 = mfma<F16>(wk0, fkv, kt0);
+        kt1 = mfma<F16>(wk1, fkv, kt1);
+        v0 = mfma<F16>(fkv, wv0, v0);
+        v1 = mfma<F16>(fkv, wv1, v1);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        red[wid][0][r][lane] = kt0[r];
+        red[wid][1][r][lane] = kt1[r];
+        red[wid][2][r][lane] = v0[r];
+        red[wid][3][r][lane] = v1[r];
+    }
+    __syncthreads();
+    // wave w finishes block w: 0, 1 = K^T dh-blocks, 2, 3 = V dh-blocks
+    float s[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = (red[0][wid][r][lane] + red[1][wid][r][lane]) + (red[2][wid][r][lane] + red[3][wid][r][lane]);
+    char *seg = a.out + ((int64_t)b * NH + h) * a.cf * FRAG;
+    if (wid < 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] += a.bk[64 * h + 32 * wid + (r & 3) + 8 * (r >> 2) + 4 * h2];       // row of the K^T block = dh
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = s[8 * sp + j];
+            *reinterpret_cast<h16x8 *>(seg + (int64_t)(kb * 4 + 2 * wid + sp) * FRAG + lane * 16) = pack8<F16, true>(e);
+        }
+    } else {
+        const int blk = wid - 2;
+        const float bv = a.bv[64 * h + 32 * blk + r31];                                                       // column of the V block = dh
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) e[j] = s[8 * t + j] + bv;
+            *reinterpret_cast<h16x8 *>(seg + (int64_t)(4 * a.kc + kb * 4 + 2 * t + blk) * FRAG + lane * 16) = pack8<F16, true>(e);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Weight packing (once per weights version): W [N rows, D] fp32 (row scale optional) -> fragments of 32 rows x 16 k with the k
+// permutation pi; fragment f of `order`: 0  W_q' [head][ks][blk] (row block 2 head + blk), 1  W_o [chunk][ks][nb] (row block 4 chunk + nb),
+// 2  K|V weights [ks][row block]
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <bool F16> __global__ void __launch_bounds__(256) k_ca_pack(const float *__restrict__ w, const float *__restrict__ colscale, int order,
+                                                                     char *__restrict__ out) {
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;        // 1152 fragments
+    int ks, rb;
+    if (order == 0) { const int hh = f / 96, rem = f % 96; ks = rem >> 1; rb = 2 * hh + (rem & 1); }
+    else if (order == 1) { const int c = f / 192, rem = f % 192; ks = rem >> 2; rb = 4 * c + (rem & 3); }
+    else { ks = f / 24; rb = f % 24; }
+    const int n = 32 * rb + (lane & 31), hb = lane >> 5;
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 16 * ks + 8 * (j >> 2) + 4 * hb + (j & 3);
+        e[j] = w[(int64_t)n * D + k] * (colscale ? colscale[k] : 1.0f);
+    }
+    *reinterpret_cast<h16x8 *>(out + (int64_t)f * FRAG + lane * 16) = pack8<F16, true>(e);
+}
+// Per-row constants of the Q projection, one wave per row n: bias' = (b_n + W_n . beta) * qscale (LayerNorm's shift folded in, scaled like
+// Q) and the row sum of the ROUNDED W'_n = round16(W_n * gamma) (the fused kernel subtracts mu * rowsum: it must be the sum of exactly the
+// operand values the MFMA sees)
+template <bool F16> __global__ void __launch_bounds__(256) k_ca_row_consts(const float *__restrict__ w, const float *__restrict__ b,
+                                                                           const float *__restrict__ gamma, const float *__restrict__ beta, float qscale,
+                                                                           float *__restrict__ bias_out, float *__restrict__ sum_out) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    float sb = 0.f, sw = 0.f;
+    for (int k = lane; k < D; k += 64) {
+        const float wv = w[(int64_t)n * D + k];
+        sb += wv * beta[k];
+        float wg = wv * gamma[k];
+        if (F16) wg = (float)(_Float16)clamp16(wg);
+        else wg = (float)(__bf16)wg;
+        sw += wg;
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) sb += __shfl_xor(sb, o), sw += __shfl_xor(sw, o);
+    if (lane == 0) {
+        bias_out[n] = (b[n] + sb) * qscale;
+        sum_out[n] = sw;
+    }
+}
+
+constexpr size_t PK_W = (size_t)D * D * 2;                    // one packed matrix
+constexpr size_t PK_WQ = 0, PK_WO = PK_W, PK_WK = 2 * PK_W, PK_WV = 3 * PK_W, PK_TABS = 4 * PK_W, PK_BK = PK_TABS + 3 * D * 4, PK_BV = PK_BK + D * 4,
+                 PK_TOTAL = PK_BV + D * 4;
+constexpr float QSCALE = 1.4426950408889634f * 0.125f;        // log2(e) / sqrt(64)
+
+inline int kc_of(int nkv) { return (nkv + 31) / 32; }
+inline int cf_of(int kc) { return (8 * kc + GROUP - 1) / GROUP * GROUP; }
+
+LvqLdsOnce g_lds_once;
+
+template <bool F16> int launch_fused(const CaArgs &a, int kc, int64_t nwg, hipStream_t st) {
+    switch (kc) {
+#define CASE(K) case K: hipLaunchKernelGGL((k_ca_fused<F16, K>), dim3((unsigned)nwg), dim3(NW * 64), LDS_BYTES, st, a); return LVQ_OK;
+        CASE(7)
+#undef CASE
+    }
+    return LVQ_EUNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int lvq_ca_fused_ok(int batch, int nq, int nkv, int d, int n_heads) {
+    return batch >= 1 && d == D && n_heads == NH && nq >= 32 && nq % 32 == 0 && nkv >= 1 && nkv <= 224;
+}
+extern "C" size_t lvq_ca_fused_packed_bytes(int d, int n_heads) { return (d == D && n_heads == NH) ? PK_TOTAL : 0; }
+extern "C" size_t lvq_ca_fused_workspace_bytes(int batch, int nq, int nkv, int d, int n_heads) {
+    if (!lvq_ca_fused_ok(batch, nq, nkv, d, n_heads)) return 0;
+    return (size_t)batch * NH * cf_of(7) * FRAG + 256;
+}
+
+extern "C" int lvq_ca_fused_pack(const float *ln_gamma, const float *ln_beta, const float *in_proj_w, const float *in_proj_b, const float *out_w,
+                                 const float *out_b, int d, int n_heads, int f16, void *packed, size_t packed_bytes, lvq_stream_t stream) {
+    if (d != D || n_heads != NH) return LVQ_EUNSUPPORTED;
+    if (!ln_gamma || !ln_beta || !in_proj_w || !in_proj_b || !out_w || !out_b || !packed) return LVQ_EINVAL;
+    if (packed_bytes < PK_TOTAL) return LVQ_EWORKSPACE;
+    hipStream_t st = lvq_s(stream);
+    char *p = (char *)packed;
+    const int nblk = D * D / (32 * 16) / 4;                   // 1152 fragments, 4 per workgroup
+    if (f16) {
+        hipLaunchKernelGGL((k_ca_pack<true>), dim3(nblk), dim3(256), 0, st, in_proj_w, ln_gamma, 0, p + PK_WQ);
+        hipLaunchKernelGGL((k_ca_pack<true>), dim3(nblk), dim3(256), 0, st, out_w, (const float *)nullptr, 1, p + PK_WO);
+        hipLaunchKernelGGL((k_ca_pack<true>), dim3(nblk), dim3(256), 0, st, in_proj_w + (size_t)D * D, (const float *)nullptr, 2, p + PK_WK);
+        hipLaunchKernelGGL((k_ca_pack<true>), dim3(nblk), dim3(256), 0, st, in_proj_w + (size_t)2 * D * D, (const float *)nullptr, 2, p + PK_WV);
+    } else {
+        hipLaunchKernelGGL((k_ca_pack<false>), dim3(nblk), dim3(256), 0, st, in_proj_w, ln_gamma, 0, p + PK_WQ);
+        hipLaunchKernelGGL((k_ca_pack<false>), dim3(nblk), dim3(256), 0, st, out_w, (const float *)nullptr, 1, p + PK_WO);
+        hipLaunchKernelGGL((k_ca_pack<false>), dim3(nblk), dim3(256), 0, st, in_proj_w + (size_t)D * D, (const float *)nullptr, 2, p + PK_WK);
+        hipLaunchKernelGGL((k_ca_pack<false>), dim3(nblk), dim3(256), 0, st, in_proj_w + (size_t)2 * D * D, (const float *)nullptr, 2, p + PK_WV);
+    }
+    float *tabs = (float *)(p + PK_TABS);
+    if (f16) hipLaunchKernelGGL((k_ca_row_consts<true>), dim3(D / 4), dim3(256), 0, st, in_proj_w, in_proj_b, ln_gamma, ln_beta, QSCALE, tabs, tabs + D);
+    else hipLaunchKernelGGL((k_ca_row_consts<false>), dim3(D / 4), dim3(256), 0, st, in_proj_w, in_proj_b, ln_gamma, ln_beta, QSCALE, tabs, tabs + D);
+    if (hipMemcpyAsync(tabs + 2 * D, out_b, D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return LVQ_ELAUNCH;
+    if (hipMemcpyAsync(p + PK_BK, in_proj_b + D, 2 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return LVQ_ELAUNCH;
+    return lvq_launch_status();
+}
+
+extern "C" int lvq_ca_fused(const float *q, const float *kv, const void *packed, float eps, int batch, int nq, int nkv, int d, int n_heads, int f16,
+                            float *out, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+    if (!lvq_ca_fused_ok(batch, nq, nkv, d, n_heads)) return LVQ_EUNSUPPORTED;
+    if (!q || !kv || !packed || !out || !ws) return LVQ_EINVAL;
+    if (ws_bytes < lvq_ca_fused_workspace_bytes(batch, nq, nkv, d, n_heads)) return LVQ_EWORKSPACE;
+    hipStream_t st = lvq_s(stream);
+    const char *p = (const char *)packed;
+    const int kc = 7, cf = cf_of(kc);              // one stream geometry (7 key blocks) for every nkv <= 224: blocks past nkv are masked
+    KvArgs ka{kv, p + PK_WK, p + PK_WV, (const float *)(p + PK_BK), (const float *)(p + PK_BV), (char *)ws, nkv, kc, cf};
+    if (f16) hipLaunchKernelGGL((k_ca_kvproj<true>), dim3(kc, NH, batch), dim3(256), 0, st, ka);
+    else hipLaunchKernelGGL((k_ca_kvproj<false>), dim3(kc, NH, batch), dim3(256), 0, st, ka);
+    if (!lvq_ensure_lds(g_lds_once, {(const void *)k_ca_fused<true, 7>, (const void *)k_ca_fused<false, 7>}, LDS_BYTES))
+        return LVQ_ELAUNCH;
+    CaArgs a;
+    a.x = q;
+    a.out = out;
+    a.wq = p + PK_WQ;
+    a.wo = p + PK_WO;
+    a.kv = (const char *)ws;
+    a.tabs = (const float *)(p + PK_TABS);
+    a.nq = nq;
+    a.nkv = nkv;
+    a.tiles_per_batch = (nq + NW * 32 - 1) / (NW * 32);
+    a.kv_batch_bytes = (int64_t)NH * cf * FRAG;
+    a.eps = eps;
+    a.qscale = QSCALE;
+    const int64_t nwg = (int64_t)batch * a.tiles_per_batch;
+    const int rc = f16 ? launch_fused<true>(a, kc, nwg, st) : launch_fused<false>(a, kc, nwg, st);
+    if (rc != LVQ_OK) return rc;
+    return lvq_launch_status();
+}

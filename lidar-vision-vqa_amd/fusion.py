@@ -186,8 +186,37 @@ class VATBlock(_HipModule):
         y, _ = ops.linear(h1, self._w(self.mlp[3].weight), self.mlp[3].bias, residual=q2, out_f32=True)
         return y
 
-    def forward_tokens(self, q2: torch.Tensor, kv_bf: BF, B: int, nq: int, nkv: int) -> torch.Tensor:
+    # ---- fused short-K/V cross-attention (csrc/cross_fused.hip): the whole `q + ca(ca_ln(q), kv, kv)` in two launches ----
+    def _ca_fused_mode(self, B: int, nq: int, nkv: int) -> Optional[bool]:
+        """None: not a shape / mode of the fused kernel; else its operand type (True = fp16, False = bf16).  "bf16" runs it on bf16
+        operands; the parity-true modes "mixed" / "mixed16" run it on fp16 operands (one MFMA pass at the bf16 rate, 4e-4 from the
+        fp32 reference at the headline shape: tools/precision_study_ca.py); "bf16x3" keeps the hi + lo chain."""
+        if os.environ.get("LVQ_NO_FUSED_CA") or not ops.ca_fused_ok(B, nq, nkv, self.d_model, self.n_heads):
+            return None
+        return {"bf16": False, "mixed": True, "mixed16": True}.get(self._mode())
+
+    def _ca_blob(self, f16: bool) -> torch.Tensor:
+        params = (self.ca_ln.weight, self.ca_ln.bias, self.ca.in_proj_weight, self.ca.in_proj_bias, self.ca.out_proj.weight, self.ca.out_proj.bias)
+        ver = tuple((p.data_ptr(), p._version, p.device) for p in params)
+        key = ("ca_fused", f16)
+        hit = self._wcache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        blob = ops.ca_fused_pack(*[_f32(p) for p in params], self.n_heads, f16)
+        self._wcache[key] = (ver, blob)
+        return blob
+
+    def _cross_attn_fused(self, q2: torch.Tensor, kv: torch.Tensor, B: int, nq: int, f16: bool) -> torch.Tensor:
+        out = ops.ca_fused(q2.view(B, nq, self.d_model), kv, self._ca_blob(f16), self.ca_ln.eps, self.n_heads, f16, tag="ca_fused")
+        return out.view(B * nq, self.d_model)
+
+    def forward_tokens(self, q2: torch.Tensor, kv_bf: Optional[BF], B: int, nq: int, nkv: int, kv_f32: Optional[torch.Tensor] = None) -> torch.Tensor:
         q2 = self._self_attn(q2, B, nq)
+        f16 = self._ca_fused_mode(B, nq, nkv) if kv_f32 is not None else None
+        if f16 is not None:
+            return self._mlp(self._cross_attn_fused(q2, kv_f32, B, nq, f16))
+        if kv_bf is None:
+            kv_bf = ops.cast(kv_f32.view(B * nkv, self.d_model), self._split())
         if kv_bf[1] is not None and self._stream_plain(nq, nkv, self.d_model // self.n_heads):
             kv_bf = (kv_bf[0], None)                     # mixed mode: the key stream's own rounding averages out
         q2 = self._cross_attn(q2, self.project_kv(kv_bf), B, nq, nkv)
@@ -198,8 +227,7 @@ class VATBlock(_HipModule):
         B, nq, d = q.shape
         nkv = kv.shape[1]
         assert d == self.d_model and kv.shape[0] == B and kv.shape[2] == d
-        kv_bf = ops.cast(_f32(kv).view(B * nkv, d), self._split())
-        out = self.forward_tokens(_f32(q).view(B * nq, d), kv_bf, B, nq, nkv)
+        out = self.forward_tokens(_f32(q).view(B * nq, d), None, B, nq, nkv, kv_f32=_f32(kv))
         return out.view(B, nq, d)
 
     def cross_attention(self, q: torch.Tensor, kv: torch.Tensor) -> torch.Tensor:
@@ -207,6 +235,9 @@ class VATBlock(_HipModule):
         self._guard(q, kv)
         B, nq, d = q.shape
         nkv = kv.shape[1]
+        f16 = self._ca_fused_mode(B, nq, nkv)
+        if f16 is not None:
+            return self._cross_attn_fused(_f32(q).view(B * nq, d), _f32(kv), B, nq, f16).view(B, nq, d)
         kv_bf = ops.cast(_f32(kv).view(B * nkv, d), self._split())
         return self._cross_attn(_f32(q).view(B * nq, d), self.project_kv(kv_bf), B, nq, nkv).view(B, nq, d)
 
@@ -427,6 +458,9 @@ class VATLiDAR(_HipModule):
                 bufs.append(buf)
             self._pe_cache[key] = (ver, bufs)
             return bufs
+        # a new table: whatever was derived from the old one (block 0's softmax totals) goes with it -- content identity is the
+        # version tuple, never the buffer address (a freed block can come back from the allocator with other contents)
+        self._pe_cache.pop(("signed_totals", H, W, dev), None)
         idx = torch.full((1, H, W), -1, dtype=torch.int32, device=dev)
         live, dirty, src, counts = ops.bev_tiles(idx, 1, H, W, dev, 0, force_all=True)
         feat = torch.zeros((1, C), dtype=torch.float32, device=dev)
@@ -463,7 +497,11 @@ class VATLiDAR(_HipModule):
         the cached totals belong to exactly these bits as long as the version key is unchanged."""
         params = [self.query, self.view_embed, blk.sa_ln.weight, blk.sa_ln.bias, blk.sa.in_proj_weight, blk.sa.in_proj_bias, blk.sa.out_proj.weight,
                   blk.sa.out_proj.bias, blk.ca_ln.weight, blk.ca_ln.bias, blk.ca.in_proj_weight, blk.ca.in_proj_bias]
-        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(), kv.data_ptr(), k_fp16)
+        # the table side of the totals: the version tuple of the K|V buffers they were computed from (all table-side parameters,
+        # precision mode, fused / k16 / route flags -- _kv_buffers), not the buffer's address
+        kv_hit = self._pe_cache.get(("kv_buffer", H, W, dev))
+        kv_ver = kv_hit[0] if kv_hit is not None and any(b is kv for b in kv_hit[1]) else ("unversioned", kv.data_ptr(), kv._version)
+        ver = tuple((p.data_ptr(), p._version) for p in params) + (self._mode(), kv_ver, k_fp16, bool(os.environ.get("LVQ_TOTALS_Q16")))
         key = ("signed_totals", H, W, dev)
         hit = self._pe_cache.get(key)
         if hit is not None and hit[0] == ver:

@@ -173,6 +173,50 @@ def attention(q: BF, k: BF, v: BF, *, batch: int, n_heads: int, n_kv_heads: int,
     return oh, ol
 
 
+def ca_fused_ok(batch: int, nq: int, nkv: int, d: int, n_heads: int) -> bool:
+    """Shapes of the fused short-K/V cross-attention kernel (include/lvq.h: lvq_ca_fused_ok)."""
+    return bool(F.lib().lvq_ca_fused_ok(F.cint(batch), F.cint(nq), F.cint(nkv), F.cint(d), F.cint(n_heads)))
+
+
+def ca_fused_pack(ln_w: torch.Tensor, ln_b: torch.Tensor, in_w: torch.Tensor, in_b: torch.Tensor, out_w: torch.Tensor, out_b: torch.Tensor,
+                  n_heads: int, f16: bool) -> torch.Tensor:
+    """ca_ln + ca weights -> the fragment-major 16-bit blob of lvq_ca_fused (once per weights version)."""
+    F.require_cuda(ln_w, ln_b, in_w, in_b, out_w, out_b)
+    d = out_w.shape[0]
+    L = F.lib()
+    nbytes = int(L.lvq_ca_fused_packed_bytes(F.cint(d), F.cint(n_heads)))
+    if nbytes == 0:
+        raise F.LvqError(f"lvq_ca_fused: d={d}, heads={n_heads} is not a shape of the fused kernel")
+    blob = torch.empty(nbytes, dtype=torch.uint8, device=out_w.device)
+    rc = L.lvq_ca_fused_pack(F.ptr(ln_w), F.ptr(ln_b), F.ptr(in_w), F.ptr(in_b), F.ptr(out_w), F.ptr(out_b), F.cint(d), F.cint(n_heads),
+                             F.cint(1 if f16 else 0), F.ptr(blob), F.csize(nbytes), F.stream_ptr(out_w.device))
+    F.check(rc, "lvq_ca_fused_pack")
+    return blob
+
+
+def ca_fused(q: torch.Tensor, kv: torch.Tensor, blob: torch.Tensor, eps: float, n_heads: int, f16: bool, tag: Optional[str] = None) -> torch.Tensor:
+    """out = q + ca(ca_ln(q), kv, kv) for q [B, nq, d], kv [B, nkv, d] fp32 (vat_blocks.py:41-42) in two launches."""
+    F.require_cuda(q, kv, blob)
+    B, nq, d = q.shape
+    nkv = kv.shape[1]
+    dev = q.device
+    L = F.lib()
+    nbytes = int(L.lvq_ca_fused_workspace_bytes(F.cint(B), F.cint(nq), F.cint(nkv), F.cint(d), F.cint(n_heads)))
+    if nbytes == 0:
+        raise F.LvqError(f"lvq_ca_fused: (B={B}, nq={nq}, nkv={nkv}, d={d}, heads={n_heads}) is not a shape of the fused kernel")
+    key = (dev.index, "ca_fused")
+    ws = _ATT_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        _ATT_WS[key] = ws
+    out = torch.empty_like(q)
+    with region(tag, dev):
+        rc = L.lvq_ca_fused(F.ptr(q), F.ptr(kv), F.ptr(blob), F.cfloat(eps), F.cint(B), F.cint(nq), F.cint(nkv), F.cint(d), F.cint(n_heads),
+                            F.cint(1 if f16 else 0), F.ptr(out), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
+    F.check(rc, f"lvq_ca_fused (B={B}, nq={nq}, nkv={nkv})")
+    return out
+
+
 def attention_stream_ok(nq: int, nkv: int, dh: int) -> bool:
     """True when lvq_attention_bf16 takes (q split, k / v plain) for this shape: the long-stream kernel's shapes."""
     return bool(F.lib().lvq_attention_stream_ok(F.cint(nq), F.cint(nkv), F.cint(dh)))
