@@ -145,19 +145,28 @@ __device__ __forceinline__ void lds_wait0(f32x4 (&f)[4]) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 // The fused kernel.  KC = 32-key blocks of the K|V stream (all scores of a row live in registers, one softmax pass; nkv <= 32 KC).
 // Fragment stream of one workgroup (groups of 16 fragments; every consumer step is a "batch" of 4 fragments = 4 MFMAs per wave):
-//   A  12 heads x [48 k-steps x 2 dh-blocks] of W_q'            72 groups
-//   B  12 heads x [K: KC x 4 | V^T: KC x 4 | pad]               12 x CG groups
-//   C   6 chunks x [48 k-steps x 4 column blocks] of W_o        72 groups
-// Registers (512 per lane, one wave per SIMD): the row's 16-bit operand fragments xd (192, phase A), Q / O of heads QL..11 (128;
+//   A  12 heads x [48 k-steps x 2 dh-blocks] of W_q'            72 groups    loop over head pairs, 48 batches per iteration
+//   B  12 heads x [K: KC x 4 | V^T: KC x 4 | pad]               12 x CG groups   loop over heads, 4 CG batches per iteration
+//   C   6 chunks x [48 k-steps x 4 column blocks] of W_o        72 groups    loop over chunks, 48 batches per iteration
+// Every loop body covers a whole number of ring revolutions (4 groups = 16 batches), so ring slots, fragment offsets and the
+// double-buffer parity are compile-time constants inside a body while the code stays a few thousand instructions per phase.
+// Registers (512 per lane, one wave per SIMD): the row's 16-bit operand fragments xd (192, phase A), Q / O of heads QL..11 (112;
 // heads 0..QL-1 live in this wave's residual area in LDS until phase C has room for them), scores (112) and P (56) of one head.
 // ---------------------------------------------------------------------------------------------------------------------------------
+
+// compile-time description of a consumer step: batches per loop body, residual pieces ride along (phase C), vector code in the body
+template <int BODY, bool RESID, bool LATE> struct StepCfg {
+    static constexpr int body_batches = BODY;
+    static constexpr bool resid = RESID, late = LATE;
+};
 
 template <bool F16, int KC>
 __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
     constexpr int CF = (8 * KC + GROUP - 1) / GROUP * GROUP;    // fragments per (batch, head) of the K|V stream
     constexpr int CG = CF / GROUP;
+    static_assert(CG == NSLOT, "a head of phase B is one ring revolution");
     constexpr int GA = NH * 6, GB = NH * CG, GC = NCHUNK * 12, GTOT = GA + GB + GC;
-    constexpr int NBT = GTOT * 4;                               // batches
+    constexpr int PA = GA * DPG, PB = GB * DPG, PTOT = GTOT * DPG;      // LDS-DMA pieces of this wave per segment
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q31 = lane & 31, h2 = lane >> 5;
@@ -172,65 +181,47 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
     const uint32_t voff = (uint32_t)(wid * FRAG + lane * 16);                        // this lane's bytes of this wave's fragments
     const char *segA = a.wq, *segC = a.wo, *segB = a.kv + (int64_t)batch * a.kv_batch_bytes;
 
-    // ---- per-column tables -> LDS (before any LDS-DMA is in flight: plain stores) ----
-    {
-        float *tab = reinterpret_cast<float *>(smem + TAB_OFF);
-        for (int i = tid; i < 3 * D; i += NW * 64) tab[i] = a.tabs[i];
-    }
-    __syncthreads();
-
-    // piece j (0 .. DPG - 1) of this wave's share of ring group G: fragment NW j + wid
-    auto issue_piece = [&](auto gi, auto ji) __attribute__((always_inline)) {
-        constexpr int G = decltype(gi)::value, j = decltype(ji)::value;
-        const char *seg = G < GA ? segA : (G < GA + GB ? segB : segC);
-        constexpr int GL = G < GA ? G : (G < GA + GB ? G - GA : G - GA - GB);
-        const char *src = seg + ((int64_t)GL * GROUP + NW * j) * FRAG + voff;
-        char *dst = smem + (G % NSLOT) * (GROUP * FRAG) + (NW * j) * FRAG + wid * FRAG;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-    };
-    auto issue_group = [&](auto gi) __attribute__((always_inline)) {
-        static_for<0, DPG>([&](auto j) { issue_piece(gi, j); });
-    };
-    static_for<0, NSLOT>([&](auto g) { issue_group(g); });       // the ring starts full: groups 0 .. NSLOT - 1
-
     // ---- LayerNorm, streaming: two lanes per row, one pass over the row, straight into B-operand fragments ----
     // lane (q, h2) holds x[q][16 ks + 8 (j >> 2) + 4 h2 + (j & 3)], j = 0..7, of every k-step (half a row).  The fragments carry
-    // d = x - c rounded to 16 bits, c = the mean of the row's first 64 elements (so |d| is a few standard deviations whatever the
+    // d = x - c rounded to 16 bits, c = the mean of the row's first 128 elements (so |d| is a few standard deviations whatever the
     // row's offset); the exact statistics of d (fp32) turn the product into LayerNorm in the Q epilogue:
     //   W' ((d - mu_d) rstd) = rstd (W' d) - (mu_d rstd) rowsum(W')          (gamma is folded into W', beta into the bias)
+    // No LDS-DMA is in flight yet: next to one, the compiler waits vmcnt(0) for every ordinary load, one HBM round trip per chunk.
     h16x8 xd[NKS];
     float q_a, q_b;                            // rstd * qscale, mu_d * rstd * qscale
     {
+        float tv[3 * D / (NW * 64)];           // the per-column tables ride along (stored to LDS after the row)
+#pragma unroll
+        for (int i = 0; i < 3 * D / (NW * 64); ++i) tv[i] = a.tabs[tid + i * NW * 64];
         const float *xr = a.x + row * D + 4 * h2;
-        constexpr int CH = 4;                  // k-steps per load chunk (8 float4 per lane)
-        f32x4 first[2 * CH];
+        constexpr int CH = 8;                  // k-steps per load chunk (16 float4 per lane)
+        f32x4 raw[2][2 * CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            first[2 * i] = *reinterpret_cast<const f32x4 *>(xr + 16 * i);
-            first[2 * i + 1] = *reinterpret_cast<const f32x4 *>(xr + 16 * i + 8);
+            raw[0][2 * i] = *reinterpret_cast<const f32x4 *>(xr + 16 * i);
+            raw[0][2 * i + 1] = *reinterpret_cast<const f32x4 *>(xr + 16 * i + 8);
         }
-        float c0 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2 * CH; ++i) c0 += (first[i][0] + first[i][1]) + (first[i][2] + first[i][3]);
-        const float cshift = swap_sum(c0) * (1.0f / (16 * CH));
-        float s1 = 0.f, s2 = 0.f;
+        float cshift = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < NKS / CH; ++c) {
-            f32x4 raw[2 * CH];
+            if (c + 1 < NKS / CH) {            // next chunk in flight while this one is converted
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                if (c == 0) {
-                    raw[2 * i] = first[2 * i], raw[2 * i + 1] = first[2 * i + 1];
-                } else {
-                    raw[2 * i] = *reinterpret_cast<const f32x4 *>(xr + 16 * (CH * c + i));
-                    raw[2 * i + 1] = *reinterpret_cast<const f32x4 *>(xr + 16 * (CH * c + i) + 8);
+                for (int i = 0; i < CH; ++i) {
+                    raw[(c + 1) & 1][2 * i] = *reinterpret_cast<const f32x4 *>(xr + 16 * (CH * (c + 1) + i));
+                    raw[(c + 1) & 1][2 * i + 1] = *reinterpret_cast<const f32x4 *>(xr + 16 * (CH * (c + 1) + i) + 8);
                 }
+            }
+            if (c == 0) {
+                float c0 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 2 * CH; ++i) c0 += (raw[0][i][0] + raw[0][i][1]) + (raw[0][i][2] + raw[0][i][3]);
+                cshift = swap_sum(c0) * (1.0f / (16 * CH));
             }
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 float e[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = raw[2 * i][j] - cshift, e[4 + j] = raw[2 * i + 1][j] - cshift;
+                for (int j = 0; j < 4; ++j) e[j] = raw[c & 1][2 * i][j] - cshift, e[4 + j] = raw[c & 1][2 * i + 1][j] - cshift;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s1 += e[j], s2 += e[j] * e[j];
                 xd[CH * c + i] = pack8<F16, true>(e);
@@ -242,78 +233,98 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
         const float rstd = 1.0f / sqrtf(var + a.eps);
         q_a = rstd * a.qscale;
         q_b = mu * q_a;
+        float *tab = reinterpret_cast<float *>(smem + TAB_OFF);
+#pragma unroll
+        for (int i = 0; i < 3 * D / (NW * 64); ++i) tab[tid + i * NW * 64] = tv[i];
     }
+    __syncthreads();
 
-    // ---- the stream ----
+    // ---- the LDS-DMA side of the stream: this wave moves piece j (fragment NW j + wid) of every group; within a segment consecutive
+    // pieces are 4 KiB apart, so the source is a running (wave-uniform) pointer ----
+    const char *sp = segA;                     // source of the next piece
+    int pc = 0;                                // pieces issued
+    auto issue_piece = [&](auto si, auto ji) __attribute__((always_inline)) {        // next piece of the stream -> ring slot si, position ji
+        constexpr int slot = decltype(si)::value, j = decltype(ji)::value;
+        if (pc < PTOT) {
+            char *dst = smem + slot * (GROUP * FRAG) + (NW * j) * FRAG + wid * FRAG;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            ++pc;
+            sp += NW * FRAG;
+            if (pc == PA) sp = segB;
+            if (pc == PA + PB) sp = segC;
+        }
+    };
+    static_for<0, NSLOT * DPG>([&](auto t) {                                         // the ring starts full: groups 0 .. NSLOT - 1
+        issue_piece(std::integral_constant<int, decltype(t)::value / DPG>{}, std::integral_constant<int, decltype(t)::value % DPG>{});
+    });
+
+    // ---- the consumer side ----
     h16x8 FA[4], FB[4];                       // two batches of fragments (the next batch is read while the current one feeds MFMAs)
     h16x8 qf[NKS];                            // Q^T as B fragments, then O^T (same slots); slots of heads < QL are filled at the start of phase C
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-    auto read4 = [&](auto bi, h16x8(&f)[4]) __attribute__((always_inline)) {
-        constexpr int GBI = decltype(bi)::value, G = GBI / 4, B4 = GBI % 4;
-        constexpr int base = (G % NSLOT) * (GROUP * FRAG) + B4 * 4 * FRAG;
-        lds_read<base>(f[0], fr_addr);
-        lds_read<base + FRAG>(f[1], fr_addr);
-        lds_read<base + 2 * FRAG>(f[2], fr_addr);
-        lds_read<base + 3 * FRAG>(f[3], fr_addr);
-    };
-    // the residual rows of out-projection chunk c, fragment u = 4 nb + g: for lane (q, h2), x[q][128 c + 32 nb + 8 g + 4 h2 .. + 3] --
+    // the residual rows of an out-projection chunk, fragment u = 4 nb + g: for lane (q, h2), x[q][128 c + 32 nb + 8 g + 4 h2 .. + 3] --
     // exactly the epilogue's operand, in the lane that needs it
-    auto issue_resid = [&](auto ci, auto ui) __attribute__((always_inline)) {
-        constexpr int c = decltype(ci)::value, u = decltype(ui)::value, nb = u >> 2, g = u & 3;
+    auto issue_resid = [&](int c, auto ui) __attribute__((always_inline)) {
+        constexpr int u = decltype(ui)::value, nb = u >> 2, g = u & 3;
         const float *src = a.x + row * D + 128 * c + 32 * nb + 8 * g + 4 * h2;
         char *dst = smem + RING_BYTES + wid * RESID_BYTES + u * FRAG;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
-    // end of ring group G (this wave has received every fragment of G it reads): group G + 1 has landed for everyone after the
-    // barrier, and the slot of G is free for group G + NSLOT, whose pieces go out one per batch from here on (`mid` below)
-    auto advance = [&](auto gi) __attribute__((always_inline)) {
-        constexpr int G = decltype(gi)::value;
-        constexpr int after = GTOT - 2 - G;                                      // groups behind G + 1
-        constexpr int inflight = after < 0 ? 0 : (after < NSLOT - 2 ? after : NSLOT - 2);
-        vm_wait<DPG * inflight>();
-        __builtin_amdgcn_s_barrier();
-    };
-    // one consumer step: batch GBI of the stream.  The body issues its four MFMAs and calls mid(0), mid(1), mid(2) between them: the
-    // requests that keep the stream going ride in the MFMAs' shadows (an MFMA holds the issue port 8 of its 32 cycles) --
+    // One consumer step = batch LB (compile time) of the current loop body; every body starts on a ring revolution (16 batches).
+    // The body issues its four MFMAs and calls mid(0), mid(1), mid(2) between them: the requests that keep the stream going ride in
+    // the MFMAs' shadows (an MFMA holds the issue port 8 of its 32 cycles) --
     //   mid(0), mid(1)  the next batch's four fragment reads
-    //   mid(2)          one LDS-DMA piece of ring group G + NSLOT - 1 (its slot was freed by the barrier at the end of group G - 1) and,
-    //                   in phase C, one piece of the chunk's residual rows
+    //   mid(2)          one LDS-DMA piece of the group three ahead (its slot was freed by the barrier at the end of the previous group)
+    //                   and, in phase C, one piece of the chunk's residual rows
+    // Before the body: this batch's reads have landed; at a group end (B4 == 3) also the counted wait for this wave's pieces of the
+    // next group and the barrier that makes everyone's pieces visible and frees the slot just finished.
     // LATE: the body carries compiler-scheduled vector code (an epilogue, the softmax) -- the next batch is then requested AFTER the
     // body: a register that an in-flight asm ds_read is about to fill looks defined to the register allocator, which under pressure
-    // may copy or spill it before the data is there (tools/check_asm_hazards.py)
-    auto step_impl = [&](auto bi, auto late, h16x8(&cur)[4], h16x8(&nxt)[4], auto &&body) __attribute__((always_inline)) {
-        constexpr int GBI = decltype(bi)::value, G = GBI / 4, B4 = GBI % 4;
-        constexpr bool has_next = GBI + 1 < NBT, LATE = decltype(late)::value;
+    // may copy or spill it before the data is there (tools/check_asm_hazards.py).
+    // last_iter: the last iteration of phase C, where the groups in flight run out (run-time, wave-uniform).
+    auto step_impl = [&](auto lbi, auto cfg, bool first3, bool last_iter, int chunk, h16x8(&cur)[4], h16x8(&nxt)[4], auto &&body) __attribute__((always_inline)) {
+        using Cfg = decltype(cfg);
+        constexpr int LB = decltype(lbi)::value, B4 = LB % 4, BODY = Cfg::body_batches;
+        constexpr bool LATE = Cfg::late, LASTB = LB == BODY - 1;
         lds_wait0(cur);
-        if constexpr (B4 == 3 && has_next) advance(std::integral_constant<int, G>{});
+        if constexpr (B4 == 3) {
+            constexpr int gl = LB / 4, groups = BODY / 4;                         // group inside the body
+            if (last_iter && gl >= groups - 3) {                                  // stream tail: 1, then 0 groups in flight behind the next one
+                if constexpr (gl == groups - 3) vm_wait<DPG>();
+                else vm_wait<0>();
+            } else {
+                vm_wait<DPG *(NSLOT - 2)>();
+            }
+            if (!(last_iter && LASTB)) __builtin_amdgcn_s_barrier();
+        }
         __builtin_amdgcn_sched_barrier(0);
+        constexpr int NB = (LB + 1) % BODY;                                       // the next batch (of this body, or batch 0 of the next iteration)
+        constexpr int nbase = ((NB / 4) % NSLOT) * (GROUP * FRAG) + (NB % 4) * 4 * FRAG;
         auto mid = [&](auto mi) __attribute__((always_inline)) {
             constexpr int m = decltype(mi)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (m < 2 && has_next && !LATE) {
-                constexpr int G1 = (GBI + 1) / 4, base = (G1 % NSLOT) * (GROUP * FRAG) + ((GBI + 1) % 4) * 4 * FRAG + 2 * m * FRAG;
-                lds_read<base>(nxt[2 * m], fr_addr);
-                lds_read<base + FRAG>(nxt[2 * m + 1], fr_addr);
+            if constexpr (m < 2 && !LATE) {
+                lds_read<nbase + 2 * m * FRAG>(nxt[2 * m], fr_addr);
+                lds_read<nbase + (2 * m + 1) * FRAG>(nxt[2 * m + 1], fr_addr);
             }
             if constexpr (m == 2) {
-                constexpr int t = GBI - 3;                                       // piece t % 4 of group t / 4 + NSLOT
-                if constexpr (t >= 0 && t / 4 + NSLOT < GTOT) issue_piece(std::integral_constant<int, t / 4 + NSLOT>{}, std::integral_constant<int, t % 4>{});
-                if constexpr (GBI >= (GA + GB) * 4) {                            // residual rows of chunk c: 16 pieces over its batches 4 .. 19
-                    constexpr int bc = GBI - (GA + GB) * 4, c = bc / NKS, u = bc % NKS - 4;
-                    if constexpr (u >= 0 && u < 16) issue_resid(std::integral_constant<int, c>{}, std::integral_constant<int, u>{});
-                }
+                constexpr int u = (LB + 13) % 16;                                 // piece u % 4 of the group that takes slot u / 4
+                if (!(first3 && LB < 3)) issue_piece(std::integral_constant<int, u / 4>{}, std::integral_constant<int, u % 4>{});
+                if constexpr (Cfg::resid && LB >= 4 && LB < 20) issue_resid(chunk, std::integral_constant<int, (LB >= 4 && LB < 20) ? LB - 4 : 0>{});
             }
             __builtin_amdgcn_sched_barrier(0);
         };
         body(cur, mid);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (has_next && LATE) read4(std::integral_constant<int, GBI + 1>{}, nxt);
-    };
-    auto step = [&](auto bi, auto late, auto &&body) __attribute__((always_inline)) {
-        constexpr int GBI = decltype(bi)::value;
-        if constexpr (GBI % 2 == 0) step_impl(bi, late, FA, FB, body);
-        else step_impl(bi, late, FB, FA, body);
+        if constexpr (LATE) {
+            if (!(last_iter && LASTB)) {
+                lds_read<nbase>(nxt[0], fr_addr);
+                lds_read<nbase + FRAG>(nxt[1], fr_addr);
+                lds_read<nbase + 2 * FRAG>(nxt[2], fr_addr);
+                lds_read<nbase + 3 * FRAG>(nxt[3], fr_addr);
+            }
+        }
     };
     const std::integral_constant<int, 0> M0{};
     const std::integral_constant<int, 1> M1{};
@@ -322,71 +333,104 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
     // group 0 has landed (this wave's pieces: counted; everyone's: barrier); first batch
     vm_wait<DPG *(NSLOT - 1)>();
     __builtin_amdgcn_s_barrier();
-    read4(std::integral_constant<int, 0>{}, FA);
+    lds_read<0>(FA[0], fr_addr);
+    lds_read<FRAG>(FA[1], fr_addr);
+    lds_read<2 * FRAG>(FA[2], fr_addr);
+    lds_read<3 * FRAG>(FA[3], fr_addr);
 
-    // ================================ A: Q^T = W_q' LN(x)^T, head by head ================================
-    static_for<0, NH>([&](auto hi) {
-        constexpr int h = decltype(hi)::value;
-        f32x16 acc0, acc1;
-        static_for<0, 24>([&](auto li) {
-            constexpr int lb = decltype(li)::value, ks = 2 * lb;
-            step(std::integral_constant<int, (h * 6) * 4 + lb>{}, std::integral_constant<bool, lb == 23>{}, [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
-                if constexpr (lb == 0) acc0 = mfma<F16>(f[0], xd[ks], zero);
-                else acc0 = mfma<F16>(f[0], xd[ks], acc0);
-                mid(M0);
-                if constexpr (lb == 0) acc1 = mfma<F16>(f[1], xd[ks], zero);
-                else acc1 = mfma<F16>(f[1], xd[ks], acc1);
-                mid(M1);
-                acc0 = mfma<F16>(f[2], xd[ks + 1], acc0);
-                mid(M2);
-                acc1 = mfma<F16>(f[3], xd[ks + 1], acc1);
-                if constexpr (lb == 23) {
-                    // Q^T (scaled by log2(e) / sqrt(dh)) = acc * q_a - rowsum(W') * q_b + bias' -> B fragments of S^T = K Q^T;
-                    // row (= dh) of register r of block blk: 32 blk + (r & 3) + 8 (r >> 2) + 4 h2
-                    static_for<0, 4>([&](auto ui) {
-                        constexpr int blk = decltype(ui)::value >> 1, sx = decltype(ui)::value & 1;
-                        f32x4 t[4];                               // t[0..1] bias', t[2..3] row sums: rows 64 h + 32 blk + 16 sx + 8 g + 4 h2 .. + 3
-                        lds_read<(64 * h + 32 * blk + 16 * sx) * 4>(t[0], tb_addr);
-                        lds_read<(64 * h + 32 * blk + 16 * sx + 8) * 4>(t[1], tb_addr);
-                        lds_read<(D + 64 * h + 32 * blk + 16 * sx) * 4>(t[2], tb_addr);
-                        lds_read<(D + 64 * h + 32 * blk + 16 * sx + 8) * 4>(t[3], tb_addr);
-                        lds_wait0(t);
-                        const f32x16 &acc = blk ? acc1 : acc0;
-                        float e[8];
+    // ================================ A: Q^T = W_q' LN(x)^T, two heads per iteration ================================
+    for (int hp = 0; hp < NH / 2; ++hp) {
+        static_for<0, 2>([&](auto hhi) {
+            constexpr int hh = decltype(hhi)::value;
+            const int h = 2 * hp + hh;
+            f32x16 acc0, acc1;
+            static_for<0, 24>([&](auto li) {
+                constexpr int lb = decltype(li)::value, ks = 2 * lb, LB = 24 * hh + lb;
+                using Cfg = StepCfg<48, false, lb == 23>;
+                auto body = [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
+                    if constexpr (lb == 0) acc0 = mfma<F16>(f[0], xd[ks], zero);
+                    else acc0 = mfma<F16>(f[0], xd[ks], acc0);
+                    mid(M0);
+                    if constexpr (lb == 0) acc1 = mfma<F16>(f[1], xd[ks], zero);
+                    else acc1 = mfma<F16>(f[1], xd[ks], acc1);
+                    mid(M1);
+                    acc0 = mfma<F16>(f[2], xd[ks + 1], acc0);
+                    mid(M2);
+                    acc1 = mfma<F16>(f[3], xd[ks + 1], acc1);
+                    if constexpr (lb == 23) {
+                        // Q^T (scaled by log2(e) / sqrt(dh)) = acc * q_a - rowsum(W') * q_b + bias' -> B fragments of S^T = K Q^T;
+                        // row (= dh) of register r of block blk: 32 blk + (r & 3) + 8 (r >> 2) + 4 h2
+                        const uint32_t th = tb_addr + h * (64 * 4);
+                        h16x8 fr[4];
+                        static_for<0, 4>([&](auto ui) {
+                            constexpr int blk = decltype(ui)::value >> 1, sx = decltype(ui)::value & 1;
+                            f32x4 t[4];                           // t[0..1] bias', t[2..3] row sums: rows 64 h + 32 blk + 16 sx + 8 g + 4 h2 .. + 3
+                            lds_read<(32 * blk + 16 * sx) * 4>(t[0], th);
+                            lds_read<(32 * blk + 16 * sx + 8) * 4>(t[1], th);
+                            lds_read<(D + 32 * blk + 16 * sx) * 4>(t[2], th);
+                            lds_read<(D + 32 * blk + 16 * sx + 8) * 4>(t[3], th);
+                            lds_wait0(t);
+                            const f32x16 &acc = blk ? acc1 : acc0;
+                            float e[8];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) e[j] = acc[8 * sx + j] * q_a + (t[j >> 2][j & 3] - t[2 + (j >> 2)][j & 3] * q_b);
-                        const h16x8 fr = pack8<F16, true>(e);
-                        if constexpr (h < QL) lds_write<(4 * h + 2 * blk + sx) * FRAG>(rs_addr, fr);
-                        else {
-                            qf[4 * h + 2 * blk + sx] = fr;
-                            pin(qf[4 * h + 2 * blk + sx]);
+                            for (int j = 0; j < 8; ++j) e[j] = acc[8 * sx + j] * q_a + (t[j >> 2][j & 3] - t[2 + (j >> 2)][j & 3] * q_b);
+                            fr[2 * blk + sx] = pack8<F16, true>(e);
+                            pin(fr[2 * blk + sx]);
+                            __builtin_amdgcn_sched_barrier(0);    // keep the four units apart (their table reads would otherwise be hoisted together)
+                        });
+                        if (h < QL) {                             // parked in LDS
+                            const uint32_t ph = rs_addr + h * (4 * FRAG);
+                            lds_write<0>(ph, fr[0]);
+                            lds_write<FRAG>(ph, fr[1]);
+                            lds_write<2 * FRAG>(ph, fr[2]);
+                            lds_write<3 * FRAG>(ph, fr[3]);
+                        } else {
+                            static_for<QL, NH>([&](auto hc) {
+                                constexpr int HC = decltype(hc)::value;
+                                if (h == HC) {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) {
+                                        qf[4 * HC + i] = fr[i];
+                                        pin(qf[4 * HC + i]);
+                                    }
+                                }
+                            });
                         }
-                        __builtin_amdgcn_sched_barrier(0);        // keep the four units apart (their table reads would otherwise be hoisted together)
-                    });
-                }
+                    }
+                };
+                if constexpr (LB % 2 == 0) step_impl(std::integral_constant<int, LB>{}, Cfg{}, hp == 0, false, 0, FA, FB, body);
+                else step_impl(std::integral_constant<int, LB>{}, Cfg{}, hp == 0, false, 0, FB, FA, body);
             });
         });
-    });
+    }
 
-    // ================================ B: attention, head by head ================================
-    static_for<0, NH>([&](auto hi) {
-        constexpr int h = decltype(hi)::value;
-        constexpr int GB0 = (GA + h * CG) * 4;                 // first batch of this head
+    // ================================ B: attention, one head per iteration ================================
+    for (int h = 0; h < NH; ++h) {
         f32x16 sacc[KC];
         h16x8 pf[KC][2];
         h16x8 qh[4];                                            // this head's Q^T fragments
         f32x16 o0, o1;
         float linv = 0.f;
-        if constexpr (h < QL) {                                 // parked Q: back from LDS (no vector code between the reads and their wait)
-            static_for<0, 4>([&](auto si) { lds_read<(4 * h + decltype(si)::value) * FRAG>(qh[decltype(si)::value], rs_addr); });
+        if (h < QL) {                                           // parked Q: back from LDS (no vector code between the reads and their wait)
+            const uint32_t ph = rs_addr + h * (4 * FRAG);
+            lds_read<0>(qh[0], ph);
+            lds_read<FRAG>(qh[1], ph);
+            lds_read<2 * FRAG>(qh[2], ph);
+            lds_read<3 * FRAG>(qh[3], ph);
             lds_wait0(qh);                                      // (also retires the first batch's reads, requested just before: harmless)
         } else {
+            static_for<QL, NH>([&](auto hc) {
+                constexpr int HC = decltype(hc)::value;
+                if (h == HC) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) qh[i] = qf[4 * h + i];
+                    for (int i = 0; i < 4; ++i) qh[i] = qf[4 * HC + i];
+                }
+            });
         }
         static_for<0, 4 * CG>([&](auto li) {
             constexpr int lb = decltype(li)::value;
-            step(std::integral_constant<int, GB0 + lb>{}, std::integral_constant<bool, lb == KC - 1 || lb == 2 * KC - 1>{}, [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
+            using Cfg = StepCfg<4 * CG, false, lb == KC - 1 || lb == 2 * KC - 1>;
+            auto body = [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
                 if constexpr (lb < KC) {                        // S^T block lb = K rows 32 lb .. + 31 against Q^T (4 k-steps over dh)
                     sacc[lb] = mfma<F16>(f[0], qh[0], zero);
                     mid(M0);
@@ -440,6 +484,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
                     mid(M2);
                     o1 = mfma<F16>(f[3], pf[kb][1], o1);
                     if constexpr (kb == KC - 1) {               // normalise -> B fragments of out^T = W_o O^T, into the slots of this head's Q
+                        h16x8 fr[4];
 #pragma unroll
                         for (int blk = 0; blk < 2; ++blk) {
                             const f32x16 &o = blk ? o1 : o0;
@@ -448,42 +493,53 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
                                 float e[8];
 #pragma unroll
                                 for (int j = 0; j < 8; ++j) e[j] = o[8 * sx + j] * linv;
-                                const h16x8 fr = pack8<F16>(e);
-                                if constexpr (h < QL) {
-                                    if (blk == 0 && sx == 0) lds_write<(4 * h + 0) * FRAG>(rs_addr, fr);
-                                    else if (blk == 0) lds_write<(4 * h + 1) * FRAG>(rs_addr, fr);
-                                    else if (sx == 0) lds_write<(4 * h + 2) * FRAG>(rs_addr, fr);
-                                    else lds_write<(4 * h + 3) * FRAG>(rs_addr, fr);
-                                } else {
-                                    qf[4 * h + 2 * blk + sx] = fr;
-                                    pin(qf[4 * h + 2 * blk + sx]);
-                                }
+                                fr[2 * blk + sx] = pack8<F16>(e);
+                                pin(fr[2 * blk + sx]);
                             }
                         }
+                        if (h < QL) {
+                            const uint32_t ph = rs_addr + h * (4 * FRAG);
+                            lds_write<0>(ph, fr[0]);
+                            lds_write<FRAG>(ph, fr[1]);
+                            lds_write<2 * FRAG>(ph, fr[2]);
+                            lds_write<3 * FRAG>(ph, fr[3]);
+                        } else {
+                            static_for<QL, NH>([&](auto hc) {
+                                constexpr int HC = decltype(hc)::value;
+                                if (h == HC) {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) {
+                                        qf[4 * HC + i] = fr[i];
+                                        pin(qf[4 * HC + i]);
+                                    }
+                                }
+                            });
+                        }
                     }
-                }
-                else {                                          // lb >= 2 KC: padding of the (batch, head) segment to whole groups
+                } else {                                        // lb >= 2 KC: padding of the (batch, head) segment to whole groups
                     mid(M0);
                     mid(M1);
                     mid(M2);
                 }
-            });
+            };
+            if constexpr (lb % 2 == 0) step_impl(std::integral_constant<int, lb>{}, Cfg{}, false, false, 0, FA, FB, body);
+            else step_impl(std::integral_constant<int, lb>{}, Cfg{}, false, false, 0, FB, FA, body);
         });
-    });
+    }
 
     // ================================ C: out^T = W_o O^T in chunks of 128 columns, + b_o + residual ================================
     // the parked O fragments of heads < QL come back first (their LDS area is about to receive the residual rows)
     static_for<0, 4 * QL>([&](auto fi) { lds_read<decltype(fi)::value * FRAG>(qf[decltype(fi)::value], rs_addr); });
 #pragma unroll
     for (int h = 0; h < QL; ++h) lds_wait0_4(qf[4 * h], qf[4 * h + 1], qf[4 * h + 2], qf[4 * h + 3]);
-    float *orow = a.out + row * D + 4 * h2;
-    static_for<0, NCHUNK>([&](auto ci) {
-        constexpr int c = decltype(ci)::value;
-        constexpr int GB0 = (GA + GB + c * 12) * 4;
+    for (int c = 0; c < NCHUNK; ++c) {
+        float *orow = a.out + row * D + 4 * h2 + 128 * c;
+        const uint32_t tbo = tb_addr + (2 * D + 128 * c) * 4;
         f32x16 acc[NBC];
         static_for<0, NKS>([&](auto ki) {
             constexpr int ks = decltype(ki)::value;
-            step(std::integral_constant<int, GB0 + ks>{}, std::integral_constant<bool, ks == NKS - 1>{}, [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
+            using Cfg = StepCfg<48, true, ks == NKS - 1>;
+            auto body = [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
                 static_for<0, NBC>([&](auto ni) {
                     constexpr int nb = decltype(ni)::value;
                     if constexpr (ks == 0) acc[nb] = mfma<F16>(f[nb], qf[ks], zero);
@@ -491,31 +547,33 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
                     if constexpr (nb < 3) mid(std::integral_constant<int, nb>{});
                 });
                 if constexpr (ks == NKS - 1) {
-        // epilogue: the residual pieces were requested >= 8 group ends ago, every ring wait since then covered them (vmcnt is in order)
-        static_for<0, NBC>([&](auto ni) {
-            constexpr int nb = decltype(ni)::value;
-            f32x4 t[8];                                      // t[g] residual, t[4 + g] bias, g = 0..3: columns 128 c + 32 nb + 8 g + 4 h2 .. + 3
-            static_for<0, 4>([&](auto gi) {
-                constexpr int g = decltype(gi)::value;
-                lds_read<(4 * nb + g) * FRAG>(t[g], rs_addr);
-                lds_read<(2 * D + 128 * c + 32 * nb + 8 * g) * 4>(t[4 + g], tb_addr);
-            });
-            lds_wait0(t);
-            if (active) {
+                    // epilogue: the residual pieces were requested >= 7 group ends ago, every ring wait since then covered them (vmcnt is in order)
+                    static_for<0, NBC>([&](auto ni) {
+                        constexpr int nb = decltype(ni)::value;
+                        f32x4 t[8];                              // t[g] residual, t[4 + g] bias, g = 0..3: columns 128 c + 32 nb + 8 g + 4 h2 .. + 3
+                        static_for<0, 4>([&](auto gi) {
+                            constexpr int g = decltype(gi)::value;
+                            lds_read<(4 * nb + g) * FRAG>(t[g], rs_addr);
+                            lds_read<(32 * nb + 8 * g) * 4>(t[4 + g], tbo);
+                        });
+                        lds_wait0(t);
+                        if (active) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 o;
+                            for (int g = 0; g < 4; ++g) {
+                                f32x4 o;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (acc[nb][4 * g + i] + t[4 + g][i]) + t[g][i];
-                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(orow + 128 * c + 32 * nb + 8 * g));
+                                for (int i = 0; i < 4; ++i) o[i] = (acc[nb][4 * g + i] + t[4 + g][i]) + t[g][i];
+                                __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(orow + 32 * nb + 8 * g));
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
                 }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            };
+            if constexpr (ks % 2 == 0) step_impl(std::integral_constant<int, ks>{}, Cfg{}, false, c == NCHUNK - 1, c, FA, FB, body);
+            else step_impl(std::integral_constant<int, ks>{}, Cfg{}, false, c == NCHUNK - 1, c, FB, FA, body);
         });
-                }
-            });
-        });
-    });
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
