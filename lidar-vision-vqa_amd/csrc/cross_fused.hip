@@ -26,6 +26,7 @@
 // is 4.3e-4 from the fp64 result at the headline shape (bf16: 3.6e-3; tolerance 1e-3), so the fp16 form is the parity-true one.
 // fp16's range is guarded where a value is not bounded by construction (kv tokens, K, V, scaled Q: clamped to +-65504).
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
@@ -130,6 +131,7 @@ struct CaArgs {
     int tiles_per_batch;     // ceil(nq / 128)
     int64_t kv_batch_bytes;
     float eps, qscale;       // qscale = log2(e) / sqrt(dh)
+    unsigned long long *stamps;   // diagnostics (LVQ_CA_STAMPS): [workgroup][wave][8] s_memrealtime ticks (100 MHz) at the phase boundaries
 };
 
 template <int OFF> __device__ __forceinline__ void lds_write(uint32_t addr, const h16x8 &d) {
@@ -160,7 +162,9 @@ template <int BODY, bool RESID, bool LATE> struct StepCfg {
     static constexpr bool resid = RESID, late = LATE;
 };
 
-template <bool F16, int KC>
+// DBG: timing experiments only (CA_DEBUG_VARIANTS builds; results are wrong): 1 no MFMA, 2 no LDS-DMA after the first ring fill,
+// 4 no fragment reads, 8 no barriers, 16 no softmax / epilogue vector code
+template <bool F16, int KC, int DBG = 0>
 __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
     constexpr int CF = (8 * KC + GROUP - 1) / GROUP * GROUP;    // fragments per (batch, head) of the K|V stream
     constexpr int CG = CF / GROUP;
@@ -180,6 +184,14 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
     const uint32_t tb_addr = sbase + TAB_OFF + h2 * 16;                              // tables: + table * 3 KiB + column * 4
     const uint32_t voff = (uint32_t)(wid * FRAG + lane * 16);                        // this lane's bytes of this wave's fragments
     const char *segA = a.wq, *segC = a.wo, *segB = a.kv + (int64_t)batch * a.kv_batch_bytes;
+    auto mfma_d = [&](const h16x8 &x, const h16x8 &y, const f32x16 &c) __attribute__((always_inline)) {
+        if constexpr (DBG & 1) return c;
+        else return mfma<F16>(x, y, c);
+    };
+    auto stamp = [&](int i) __attribute__((always_inline)) {
+        if (a.stamps && lane == 0) a.stamps[((int64_t)blockIdx.x * NW + wid) * 8 + i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
 
     // ---- LayerNorm, streaming: two lanes per row, one pass over the row, straight into B-operand fragments ----
     // lane (q, h2) holds x[q][16 ks + 8 (j >> 2) + 4 h2 + (j & 3)], j = 0..7, of every k-step (half a row).  The fragments carry
@@ -238,21 +250,22 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
         for (int i = 0; i < 3 * D / (NW * 64); ++i) tab[tid + i * NW * 64] = tv[i];
     }
     __syncthreads();
+    stamp(1);
 
     // ---- the LDS-DMA side of the stream: this wave moves piece j (fragment NW j + wid) of every group; within a segment consecutive
     // pieces are 4 KiB apart, so the source is a running (wave-uniform) pointer ----
     const char *sp = segA;                     // source of the next piece
     int pc = 0;                                // pieces issued
+    // (no branch in here: the scalar bookkeeping sits between two MFMAs of a batch, and a taken branch costs more than their shadow)
     auto issue_piece = [&](auto si, auto ji) __attribute__((always_inline)) {        // next piece of the stream -> ring slot si, position ji
         constexpr int slot = decltype(si)::value, j = decltype(ji)::value;
-        if (pc < PTOT) {
-            char *dst = smem + slot * (GROUP * FRAG) + (NW * j) * FRAG + wid * FRAG;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
-            ++pc;
-            sp += NW * FRAG;
-            if (pc == PA) sp = segB;
-            if (pc == PA + PB) sp = segC;
-        }
+        char *dst = smem + slot * (GROUP * FRAG) + (NW * j) * FRAG + wid * FRAG;
+        if (!((DBG & 2) && pc >= NSLOT * DPG))
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sp + voff), (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        ++pc;
+        sp += NW * FRAG;
+        sp = pc == PA ? segB : sp;
+        sp = pc == PA + PB ? segC : sp;
     };
     static_for<0, NSLOT * DPG>([&](auto t) {                                         // the ring starts full: groups 0 .. NSLOT - 1
         issue_piece(std::integral_constant<int, decltype(t)::value / DPG>{}, std::integral_constant<int, decltype(t)::value % DPG>{});
@@ -296,7 +309,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
             } else {
                 vm_wait<DPG *(NSLOT - 2)>();
             }
-            if (!(last_iter && LASTB)) __builtin_amdgcn_s_barrier();
+            if constexpr (!(DBG & 8)) if (!(last_iter && LASTB)) __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
         constexpr int NB = (LB + 1) % BODY;                                       // the next batch (of this body, or batch 0 of the next iteration)
@@ -304,13 +317,20 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
         auto mid = [&](auto mi) __attribute__((always_inline)) {
             constexpr int m = decltype(mi)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (m < 2 && !LATE) {
+            if constexpr (m < 2 && !LATE && !(DBG & 4)) {
                 lds_read<nbase + 2 * m * FRAG>(nxt[2 * m], fr_addr);
                 lds_read<nbase + (2 * m + 1) * FRAG>(nxt[2 * m + 1], fr_addr);
             }
             if constexpr (m == 2) {
                 constexpr int u = (LB + 13) % 16;                                 // piece u % 4 of the group that takes slot u / 4
-                if (!(first3 && LB < 3)) issue_piece(std::integral_constant<int, u / 4>{}, std::integral_constant<int, u % 4>{});
+                // pieces go out at batches 3 .. PTOT + 2 of the stream: not in its first three batches, not in its last 13
+                if constexpr (LB < 3) {
+                    if (!first3) issue_piece(std::integral_constant<int, u / 4>{}, std::integral_constant<int, u % 4>{});
+                } else if constexpr (LB >= BODY - 13) {
+                    if (!last_iter) issue_piece(std::integral_constant<int, u / 4>{}, std::integral_constant<int, u % 4>{});
+                } else {
+                    issue_piece(std::integral_constant<int, u / 4>{}, std::integral_constant<int, u % 4>{});
+                }
                 if constexpr (Cfg::resid && LB >= 4 && LB < 20) issue_resid(chunk, std::integral_constant<int, (LB >= 4 && LB < 20) ? LB - 4 : 0>{});
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -338,6 +358,8 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
     lds_read<2 * FRAG>(FA[2], fr_addr);
     lds_read<3 * FRAG>(FA[3], fr_addr);
 
+    stamp(2);
+    if (a.stamps && lane == 0) a.stamps[((int64_t)blockIdx.x * NW + wid) * 8 + 6] = __builtin_amdgcn_s_memtime();
     // ================================ A: Q^T = W_q' LN(x)^T, two heads per iteration ================================
     for (int hp = 0; hp < NH / 2; ++hp) {
         static_for<0, 2>([&](auto hhi) {
@@ -348,16 +370,16 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
                 constexpr int lb = decltype(li)::value, ks = 2 * lb, LB = 24 * hh + lb;
                 using Cfg = StepCfg<48, false, lb == 23>;
                 auto body = [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
-                    if constexpr (lb == 0) acc0 = mfma<F16>(f[0], xd[ks], zero);
-                    else acc0 = mfma<F16>(f[0], xd[ks], acc0);
+                    if constexpr (lb == 0) acc0 = mfma_d(f[0], xd[ks], zero);
+                    else acc0 = mfma_d(f[0], xd[ks], acc0);
                     mid(M0);
-                    if constexpr (lb == 0) acc1 = mfma<F16>(f[1], xd[ks], zero);
-                    else acc1 = mfma<F16>(f[1], xd[ks], acc1);
+                    if constexpr (lb == 0) acc1 = mfma_d(f[1], xd[ks], zero);
+                    else acc1 = mfma_d(f[1], xd[ks], acc1);
                     mid(M1);
-                    acc0 = mfma<F16>(f[2], xd[ks + 1], acc0);
+                    acc0 = mfma_d(f[2], xd[ks + 1], acc0);
                     mid(M2);
-                    acc1 = mfma<F16>(f[3], xd[ks + 1], acc1);
-                    if constexpr (lb == 23) {
+                    acc1 = mfma_d(f[3], xd[ks + 1], acc1);
+                    if constexpr (lb == 23 && !(DBG & 16)) {
                         // Q^T (scaled by log2(e) / sqrt(dh)) = acc * q_a - rowsum(W') * q_b + bias' -> B fragments of S^T = K Q^T;
                         // row (= dh) of register r of block blk: 32 blk + (r & 3) + 8 (r >> 2) + 4 h2
                         const uint32_t th = tb_addr + h * (64 * 4);
@@ -404,6 +426,8 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
         });
     }
 
+    stamp(3);
+    if (a.stamps && lane == 0) a.stamps[((int64_t)blockIdx.x * NW + wid) * 8 + 7] = __builtin_amdgcn_s_memtime();
     // ================================ B: attention, one head per iteration ================================
     for (int h = 0; h < NH; ++h) {
         f32x16 sacc[KC];
@@ -432,14 +456,14 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
             using Cfg = StepCfg<4 * CG, false, lb == KC - 1 || lb == 2 * KC - 1>;
             auto body = [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
                 if constexpr (lb < KC) {                        // S^T block lb = K rows 32 lb .. + 31 against Q^T (4 k-steps over dh)
-                    sacc[lb] = mfma<F16>(f[0], qh[0], zero);
+                    sacc[lb] = mfma_d(f[0], qh[0], zero);
                     mid(M0);
-                    sacc[lb] = mfma<F16>(f[1], qh[1], sacc[lb]);
+                    sacc[lb] = mfma_d(f[1], qh[1], sacc[lb]);
                     mid(M1);
-                    sacc[lb] = mfma<F16>(f[2], qh[2], sacc[lb]);
+                    sacc[lb] = mfma_d(f[2], qh[2], sacc[lb]);
                     mid(M2);
-                    sacc[lb] = mfma<F16>(f[3], qh[3], sacc[lb]);
-                    if constexpr (lb == KC - 1) {               // softmax over the row's keys: 16 KC scores in this lane + as many in lane ^ 32
+                    sacc[lb] = mfma_d(f[3], qh[3], sacc[lb]);
+                    if constexpr (lb == KC - 1 && !(DBG & 16)) {               // softmax over the row's keys: 16 KC scores in this lane + as many in lane ^ 32
 #pragma unroll
                         for (int kb = 0; kb < KC; ++kb) {
                             if (32 * (kb + 1) > a.nkv) {        // (wave-uniform) block with keys past nkv
@@ -474,16 +498,16 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
                     }
                 } else if constexpr (lb < 2 * KC) {             // O^T += V^T P^T over key block kb (2 k-steps x 2 dh-blocks)
                     constexpr int kb = lb - KC;
-                    if constexpr (kb == 0) o0 = mfma<F16>(f[0], pf[kb][0], zero);
-                    else o0 = mfma<F16>(f[0], pf[kb][0], o0);
+                    if constexpr (kb == 0) o0 = mfma_d(f[0], pf[kb][0], zero);
+                    else o0 = mfma_d(f[0], pf[kb][0], o0);
                     mid(M0);
-                    if constexpr (kb == 0) o1 = mfma<F16>(f[1], pf[kb][0], zero);
-                    else o1 = mfma<F16>(f[1], pf[kb][0], o1);
+                    if constexpr (kb == 0) o1 = mfma_d(f[1], pf[kb][0], zero);
+                    else o1 = mfma_d(f[1], pf[kb][0], o1);
                     mid(M1);
-                    o0 = mfma<F16>(f[2], pf[kb][1], o0);
+                    o0 = mfma_d(f[2], pf[kb][1], o0);
                     mid(M2);
-                    o1 = mfma<F16>(f[3], pf[kb][1], o1);
-                    if constexpr (kb == KC - 1) {               // normalise -> B fragments of out^T = W_o O^T, into the slots of this head's Q
+                    o1 = mfma_d(f[3], pf[kb][1], o1);
+                    if constexpr (kb == KC - 1 && !(DBG & 16)) {               // normalise -> B fragments of out^T = W_o O^T, into the slots of this head's Q
                         h16x8 fr[4];
 #pragma unroll
                         for (int blk = 0; blk < 2; ++blk) {
@@ -527,6 +551,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
         });
     }
 
+    stamp(4);
     // ================================ C: out^T = W_o O^T in chunks of 128 columns, + b_o + residual ================================
     // the parked O fragments of heads < QL come back first (their LDS area is about to receive the residual rows)
     static_for<0, 4 * QL>([&](auto fi) { lds_read<decltype(fi)::value * FRAG>(qf[decltype(fi)::value], rs_addr); });
@@ -542,11 +567,11 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
             auto body = [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
                 static_for<0, NBC>([&](auto ni) {
                     constexpr int nb = decltype(ni)::value;
-                    if constexpr (ks == 0) acc[nb] = mfma<F16>(f[nb], qf[ks], zero);
-                    else acc[nb] = mfma<F16>(f[nb], qf[ks], acc[nb]);
+                    if constexpr (ks == 0) acc[nb] = mfma_d(f[nb], qf[ks], zero);
+                    else acc[nb] = mfma_d(f[nb], qf[ks], acc[nb]);
                     if constexpr (nb < 3) mid(std::integral_constant<int, nb>{});
                 });
-                if constexpr (ks == NKS - 1) {
+                if constexpr (ks == NKS - 1 && !(DBG & 16)) {
                     // epilogue: the residual pieces were requested >= 7 group ends ago, every ring wait since then covered them (vmcnt is in order)
                     static_for<0, NBC>([&](auto ni) {
                         constexpr int nb = decltype(ni)::value;
@@ -574,6 +599,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
             else step_impl(std::integral_constant<int, ks>{}, Cfg{}, false, c == NCHUNK - 1, c, FB, FA, body);
         });
     }
+    stamp(5);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -705,7 +731,29 @@ inline int cf_of(int kc) { return (8 * kc + GROUP - 1) / GROUP * GROUP; }
 
 LvqLdsOnce g_lds_once;
 
+#ifdef CA_DEBUG_VARIANTS
+template <int DBG> void launch_dbg(const CaArgs &a, int64_t nwg, hipStream_t st) {
+    hipFuncSetAttribute((const void *)k_ca_fused<true, 7, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipLaunchKernelGGL((k_ca_fused<true, 7, DBG>), dim3((unsigned)nwg), dim3(NW * 64), LDS_BYTES, st, a);
+}
+#endif
 template <bool F16> int launch_fused(const CaArgs &a, int kc, int64_t nwg, hipStream_t st) {
+#ifdef CA_DEBUG_VARIANTS
+    if (const char *e = getenv("LVQ_CA_DBG")) {
+        switch (atoi(e)) {
+            case 1: launch_dbg<1>(a, nwg, st); return LVQ_OK;
+            case 2: launch_dbg<2>(a, nwg, st); return LVQ_OK;
+            case 4: launch_dbg<4>(a, nwg, st); return LVQ_OK;
+            case 8: launch_dbg<8>(a, nwg, st); return LVQ_OK;
+            case 16: launch_dbg<16>(a, nwg, st); return LVQ_OK;
+            case 6: launch_dbg<6>(a, nwg, st); return LVQ_OK;
+            case 14: launch_dbg<14>(a, nwg, st); return LVQ_OK;
+            case 30: launch_dbg<30>(a, nwg, st); return LVQ_OK;
+            case 31: launch_dbg<31>(a, nwg, st); return LVQ_OK;
+            case 29: launch_dbg<29>(a, nwg, st); return LVQ_OK;
+        }
+    }
+#endif
     switch (kc) {
 #define CASE(K) case K: hipLaunchKernelGGL((k_ca_fused<F16, K>), dim3((unsigned)nwg), dim3(NW * 64), LDS_BYTES, st, a); return LVQ_OK;
         CASE(7)
@@ -778,6 +826,10 @@ extern "C" int lvq_ca_fused(const float *q, const float *kv, const void *packed,
     a.kv_batch_bytes = (int64_t)NH * cf * FRAG;
     a.eps = eps;
     a.qscale = QSCALE;
+    {
+        const char *e = getenv("LVQ_CA_STAMPS");          // diagnostics: a device pointer (decimal) to [workgroups][4][8] uint64
+        a.stamps = e ? (unsigned long long *)strtoull(e, nullptr, 10) : nullptr;
+    }
     const int64_t nwg = (int64_t)batch * a.tiles_per_batch;
     const int rc = f16 ? launch_fused<true>(a, kc, nwg, st) : launch_fused<false>(a, kc, nwg, st);
     if (rc != LVQ_OK) return rc;
