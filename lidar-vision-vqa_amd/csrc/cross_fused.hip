@@ -51,6 +51,7 @@ constexpr int QL = 5;                       // heads whose Q / O fragments wait 
 constexpr int RESID_BYTES = (4 * QL > GROUP ? 4 * QL : GROUP) * FRAG;   // per wave: parked Q / O fragments, then (phase C) 32 rows x 128 columns fp32
 constexpr int TAB_OFF = RING_BYTES + NW * RESID_BYTES;   // three [768] fp32 tables: bias' of Q, row sums of W_q', b_o
 constexpr int LDS_BYTES = TAB_OFF + 3 * D * 4;
+constexpr int RPITCH = FRAG + 16;            // LDS pitch of a residual piece (two 512-byte row segments + pad)
 constexpr int NBC = 4;                      // 32-column blocks per out-projection chunk (128 columns)
 constexpr int NCHUNK = D / (32 * NBC);      // 6
 
@@ -134,6 +135,9 @@ struct CaArgs {
     unsigned long long *stamps;   // diagnostics (LVQ_CA_STAMPS): [workgroup][wave][8] s_memrealtime ticks (100 MHz) at the phase boundaries
 };
 
+template <int OFF> __device__ __forceinline__ void lds_write(uint32_t addr, const f32x4 &d) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(d), "n"(OFF) : "memory");
+}
 template <int OFF> __device__ __forceinline__ void lds_write(uint32_t addr, const h16x8 &d) {
     asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(d), "n"(OFF) : "memory");
 }
@@ -276,12 +280,14 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
     h16x8 qf[NKS];                            // Q^T as B fragments, then O^T (same slots); slots of heads < QL are filled at the start of phase C
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-    // the residual rows of an out-projection chunk, fragment u = 4 nb + g: for lane (q, h2), x[q][128 c + 32 nb + 8 g + 4 h2 .. + 3] --
-    // exactly the epilogue's operand, in the lane that needs it
+    // the residual rows of an out-projection chunk as 16 pieces of two FULL 512-byte row segments each: piece u = rows u and u + 16 of this
+    // wave (lane l: row u + 16 (l >> 5), floats 4 (l & 31) .. + 3 of the chunk's 128 columns).  LDS image: piece u at u * RPITCH, i.e.
+    // row r at (r & 15) * RPITCH + (r >> 4) * 512 -- the 16-byte pad per piece makes the epilogue's column-wise accesses (32 rows at
+    // one column offset) conflict-free
     auto issue_resid = [&](int c, auto ui) __attribute__((always_inline)) {
-        constexpr int u = decltype(ui)::value, nb = u >> 2, g = u & 3;
-        const float *src = a.x + row * D + 128 * c + 32 * nb + 8 * g + 4 * h2;
-        char *dst = smem + RING_BYTES + wid * RESID_BYTES + u * FRAG;
+        constexpr int u = decltype(ui)::value;
+        const float *src = a.x + ((int64_t)batch * a.nq + (active ? r0 : 0) + u + 16 * h2) * D + 128 * c + 4 * q31;
+        char *dst = smem + RING_BYTES + wid * RESID_BYTES + u * RPITCH;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
     };
     // One consumer step = batch LB (compile time) of the current loop body; every body starts on a ring revolution (16 batches).
@@ -361,10 +367,11 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
     stamp(2);
     if (a.stamps && lane == 0) a.stamps[((int64_t)blockIdx.x * NW + wid) * 8 + 6] = __builtin_amdgcn_s_memtime();
     // ================================ A: Q^T = W_q' LN(x)^T, two heads per iteration ================================
-    for (int hp = 0; hp < NH / 2; ++hp) {
+    static_for<0, NH / 2>([&](auto hpi) {
+        constexpr int hp = decltype(hpi)::value;
         static_for<0, 2>([&](auto hhi) {
             constexpr int hh = decltype(hhi)::value;
-            const int h = 2 * hp + hh;
+            constexpr int h = 2 * hp + hh;
             f32x16 acc0, acc1;
             static_for<0, 24>([&](auto li) {
                 constexpr int lb = decltype(li)::value, ks = 2 * lb, LB = 24 * hh + lb;
@@ -395,7 +402,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
                             const f32x16 &acc = blk ? acc1 : acc0;
                             float e[8];
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) e[j] = acc[8 * sx + j] * q_a + (t[j >> 2][j & 3] - t[2 + (j >> 2)][j & 3] * q_b);
+                            for (int j = 0; j < 8; ++j) e[j] = __builtin_fmaf(acc[8 * sx + j], q_a, __builtin_fmaf(-t[2 + (j >> 2)][j & 3], q_b, t[j >> 2][j & 3]));
                             fr[2 * blk + sx] = pack8<F16, true>(e);
                             pin(fr[2 * blk + sx]);
                             __builtin_amdgcn_sched_barrier(0);    // keep the four units apart (their table reads would otherwise be hoisted together)
@@ -424,12 +431,18 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
                 else step_impl(std::integral_constant<int, LB>{}, Cfg{}, hp == 0, false, 0, FB, FA, body);
             });
         });
-    }
+    });
 
     stamp(3);
     if (a.stamps && lane == 0) a.stamps[((int64_t)blockIdx.x * NW + wid) * 8 + 7] = __builtin_amdgcn_s_memtime();
+    // keys past nkv exist in the LAST key block only (32 (KC - 1) < nkv <= 32 KC, checked by the host): its score accumulators start at
+    // -inf for those keys instead of 0, so the softmax needs no masking code at all
+    f32x16 cpart;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cpart[r] = (32 * (KC - 1) + (r & 3) + 8 * (r >> 2) + 4 * h2) < a.nkv ? 0.f : -INFINITY;
     // ================================ B: attention, one head per iteration ================================
-    for (int h = 0; h < NH; ++h) {
+    static_for<0, NH>([&](auto hi) {
+        constexpr int h = decltype(hi)::value;
         f32x16 sacc[KC];
         h16x8 pf[KC][2];
         h16x8 qh[4];                                            // this head's Q^T fragments
@@ -456,7 +469,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
             using Cfg = StepCfg<4 * CG, false, lb == KC - 1 || lb == 2 * KC - 1>;
             auto body = [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
                 if constexpr (lb < KC) {                        // S^T block lb = K rows 32 lb .. + 31 against Q^T (4 k-steps over dh)
-                    sacc[lb] = mfma_d(f[0], qh[0], zero);
+                    sacc[lb] = mfma_d(f[0], qh[0], lb == KC - 1 ? cpart : zero);
                     mid(M0);
                     sacc[lb] = mfma_d(f[1], qh[1], sacc[lb]);
                     mid(M1);
@@ -464,16 +477,6 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
                     mid(M2);
                     sacc[lb] = mfma_d(f[3], qh[3], sacc[lb]);
                     if constexpr (lb == KC - 1 && !(DBG & 16)) {               // softmax over the row's keys: 16 KC scores in this lane + as many in lane ^ 32
-#pragma unroll
-                        for (int kb = 0; kb < KC; ++kb) {
-                            if (32 * (kb + 1) > a.nkv) {        // (wave-uniform) block with keys past nkv
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) {
-                                    const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h2;
-                                    sacc[kb][r] = key < a.nkv ? sacc[kb][r] : -INFINITY;
-                                }
-                            }
-                        }
                         float m = -INFINITY;
 #pragma unroll
                         for (int kb = 0; kb < KC; ++kb)
@@ -549,7 +552,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
             if constexpr (lb % 2 == 0) step_impl(std::integral_constant<int, lb>{}, Cfg{}, false, false, 0, FA, FB, body);
             else step_impl(std::integral_constant<int, lb>{}, Cfg{}, false, false, 0, FB, FA, body);
         });
-    }
+    });
 
     stamp(4);
     // ================================ C: out^T = W_o O^T in chunks of 128 columns, + b_o + residual ================================
@@ -558,8 +561,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
 #pragma unroll
     for (int h = 0; h < QL; ++h) lds_wait0_4(qf[4 * h], qf[4 * h + 1], qf[4 * h + 2], qf[4 * h + 3]);
     for (int c = 0; c < NCHUNK; ++c) {
-        float *orow = a.out + row * D + 4 * h2 + 128 * c;
-        const uint32_t tbo = tb_addr + (2 * D + 128 * c) * 4;
+            const uint32_t tbo = tb_addr + (2 * D + 128 * c) * 4;
         f32x16 acc[NBC];
         static_for<0, NKS>([&](auto ki) {
             constexpr int ks = decltype(ki)::value;
@@ -572,24 +574,37 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
                     if constexpr (nb < 3) mid(std::integral_constant<int, nb>{});
                 });
                 if constexpr (ks == NKS - 1 && !(DBG & 16)) {
-                    // epilogue: the residual pieces were requested >= 7 group ends ago, every ring wait since then covered them (vmcnt is in order)
+                    // epilogue.  The residual pieces were requested >= 7 group ends ago, every ring wait since then covered them (vmcnt
+                    // is in order).  (1) out^T (lane = row, registers = columns) + bias is added INTO the residual tile in LDS, column-wise;
+                    // (2) the tile leaves row-wise: every store instruction writes two full 512-byte row segments.
+                    const uint32_t tq = rs_addr - lane * 16 + (q31 & 15) * RPITCH + (q31 >> 4) * 512 + h2 * 16;     // this lane's row, + 16 B for h2
                     static_for<0, NBC>([&](auto ni) {
                         constexpr int nb = decltype(ni)::value;
                         f32x4 t[8];                              // t[g] residual, t[4 + g] bias, g = 0..3: columns 128 c + 32 nb + 8 g + 4 h2 .. + 3
                         static_for<0, 4>([&](auto gi) {
                             constexpr int g = decltype(gi)::value;
-                            lds_read<(4 * nb + g) * FRAG>(t[g], rs_addr);
+                            lds_read<(32 * nb + 8 * g) * 4>(t[g], tq);
                             lds_read<(32 * nb + 8 * g) * 4>(t[4 + g], tbo);
                         });
                         lds_wait0(t);
+                        static_for<0, 4>([&](auto gi) {
+                            constexpr int g = decltype(gi)::value;
+                            f32x4 o;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) o[i] = (acc[nb][4 * g + i] + t[4 + g][i]) + t[g][i];
+                            lds_write<(32 * nb + 8 * g) * 4>(tq, o);
+                        });
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    float *ob = a.out + ((int64_t)batch * a.nq + r0 + 16 * h2) * D + 128 * c + 4 * q31;
+                    static_for<0, 4>([&](auto vi) {
+                        constexpr int v4 = decltype(vi)::value;
+                        f32x4 t[4];
+                        static_for<0, 4>([&](auto ji) { lds_read<(4 * v4 + decltype(ji)::value) * RPITCH>(t[decltype(ji)::value], rs_addr); });
+                        lds_wait0(t);
                         if (active) {
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) {
-                                f32x4 o;
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) o[i] = (acc[nb][4 * g + i] + t[4 + g][i]) + t[g][i];
-                                __builtin_nontemporal_store(o, reinterpret_cast<f32x4 *>(orow + 32 * nb + 8 * g));
-                            }
+                            for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(t[j], reinterpret_cast<f32x4 *>(ob + (int64_t)(4 * v4 + j) * D));
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     });
@@ -605,7 +620,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 // K|V projection of the kv tokens straight into fragment order.  One workgroup per (key block, head, batch): K^T block = W_k kv^T
 // (accumulator = the K fragment of the fused kernel's S^T = K Q^T: registers 8 s .. 8 s + 7 of dh-block b are fragment 2 b + s) and
-// V block = kv W_v^T (registers 8 t .. 8 t + 7 of dh-block b are the V^T fragment (t, b)).  4 waves split the 48 k-steps, sums via LDS.
+// V block = kv W_v^T (registers 8 t .. 8 t + 7 of dh-block b are the V^T fragment (t, b)).  8 waves split the 48 k-steps, sums via LDS.
 // ---------------------------------------------------------------------------------------------------------------------------------
 struct KvArgs {
     const float *kv;        // [B, nkv, D] fp32
@@ -615,8 +630,10 @@ struct KvArgs {
     int nkv, kc, cf;
 };
 
-template <bool F16> __global__ void __launch_bounds__(256) k_ca_kvproj(KvArgs a) {
-    __shared__ float red[4][4][16][64];                      // [wave][block][register][lane]
+constexpr int KVW = 8;                       // waves per workgroup of the K|V projection: 6 k-steps each, every load of a wave in flight at once
+
+template <bool F16> __global__ void __launch_bounds__(KVW * 64) k_ca_kvproj(KvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [wave][block][register][lane]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, r31 = lane & 31, h2 = lane >> 5;
     const int kb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int key = 32 * kb + r31;
@@ -624,34 +641,50 @@ template <bool F16> __global__ void __launch_bounds__(256) k_ca_kvproj(KvArgs a)
     const float *kr = a.kv + ((int64_t)b * a.nkv + (valid ? key : 0)) * D + 4 * h2;
     const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     f32x16 kt0 = zero, kt1 = zero, v0 = zero, v1 = zero;
-#pragma unroll 4
-    for (int i = 0; i < NKS / 4; ++i) {
-        const int ks = wid + 4 * i;
-        f32x4 x0 = *reinterpret_cast<const f32x4 *>(kr + 16 * ks), x1 = *reinterpret_cast<const f32x4 *>(kr + 16 * ks + 8);
+    constexpr int NS = NKS / KVW;
+    f32x4 x0[NS], x1[NS];
+    h16x8 wk0[NS], wk1[NS], wv0[NS], wv1[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int ks = wid + KVW * i;
+        x0[i] = *reinterpret_cast<const f32x4 *>(kr + 16 * ks);
+        x1[i] = *reinterpret_cast<const f32x4 *>(kr + 16 * ks + 8);
+        const int64_t fo = ((int64_t)(ks * 24 + 2 * h) * 64 + lane) * 16;
+        wk0[i] = *reinterpret_cast<const h16x8 *>(a.wk + fo);
+        wk1[i] = *reinterpret_cast<const h16x8 *>(a.wk + fo + FRAG);
+        wv0[i] = *reinterpret_cast<const h16x8 *>(a.wv + fo);
+        wv1[i] = *reinterpret_cast<const h16x8 *>(a.wv + fo + FRAG);
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
         float e[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) e[j] = valid ? x0[j] : 0.f, e[4 + j] = valid ? x1[j] : 0.f;
+        for (int j = 0; j < 4; ++j) e[j] = valid ? x0[i][j] : 0.f, e[4 + j] = valid ? x1[i][j] : 0.f;
         const h16x8 fkv = pack8<F16, true>(e);
-        const int64_t fo = ((int64_t)(ks * 24 + 2 * h) * 64 + lane) * 16;
-        const h16x8 wk0 = *reinterpret_cast<const h16x8 *>(a.wk + fo), wk1 = *reinterpret_cast<const h16x8 *>(a.wk + fo + FRAG);
-        const h16x8 wv0 = *reinterpret_cast<const h16x8 *>(a.wv + fo), wv1 = *reinterpret_cast<const h16x8 *>(a.wv + fo + FRAG);
-        kt0 = mfma<F16>(wk0, fkv, kt0);
-        kt1 = mfma<F16>(wk1, fkv, kt1);
-        v0 = mfma<F16>(fkv, wv0, v0);
-        v1 = mfma<F16>(fkv, wv1, v1);
+        kt0 = mfma<F16>(wk0[i], fkv, kt0);
+        kt1 = mfma<F16>(wk1[i], fkv, kt1);
+        v0 = mfma<F16>(fkv, wv0[i], v0);
+        v1 = mfma<F16>(fkv, wv1[i], v1);
     }
+    float *mine = red + (size_t)wid * 4 * 16 * 64;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        red[wid][0][r][lane] = kt0[r];
-        red[wid][1][r][lane] = kt1[r];
-        red[wid][2][r][lane] = v0[r];
-        red[wid][3][r][lane] = v1[r];
+        mine[(0 * 16 + r) * 64 + lane] = kt0[r];
+        mine[(1 * 16 + r) * 64 + lane] = kt1[r];
+        mine[(2 * 16 + r) * 64 + lane] = v0[r];
+        mine[(3 * 16 + r) * 64 + lane] = v1[r];
     }
     __syncthreads();
+    if (wid >= 4) return;
     // wave w finishes block w: 0, 1 = K^T dh-blocks, 2, 3 = V dh-blocks
     float s[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = (red[0][wid][r][lane] + red[1][wid][r][lane]) + (red[2][wid][r][lane] + red[3][wid][r][lane]);
+    for (int r = 0; r < 16; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < KVW; ++w) t += red[((size_t)(w * 4 + wid) * 16 + r) * 64 + lane];
+        s[r] = t;
+    }
     char *seg = a.out + ((int64_t)b * NH + h) * a.cf * FRAG;
     if (wid < 2) {
 #pragma unroll
@@ -765,7 +798,7 @@ template <bool F16> int launch_fused(const CaArgs &a, int kc, int64_t nwg, hipSt
 }  // namespace
 
 extern "C" int lvq_ca_fused_ok(int batch, int nq, int nkv, int d, int n_heads) {
-    return batch >= 1 && d == D && n_heads == NH && nq >= 32 && nq % 32 == 0 && nkv >= 1 && nkv <= 224;
+    return batch >= 1 && d == D && n_heads == NH && nq >= 32 && nq % 32 == 0 && nkv > 192 && nkv <= 224;   // KC = 7 instantiated
 }
 extern "C" size_t lvq_ca_fused_packed_bytes(int d, int n_heads) { return (d == D && n_heads == NH) ? PK_TOTAL : 0; }
 extern "C" size_t lvq_ca_fused_workspace_bytes(int batch, int nq, int nkv, int d, int n_heads) {
@@ -807,10 +840,13 @@ extern "C" int lvq_ca_fused(const float *q, const float *kv, const void *packed,
     if (ws_bytes < lvq_ca_fused_workspace_bytes(batch, nq, nkv, d, n_heads)) return LVQ_EWORKSPACE;
     hipStream_t st = lvq_s(stream);
     const char *p = (const char *)packed;
-    const int kc = 7, cf = cf_of(kc);              // one stream geometry (7 key blocks) for every nkv <= 224: blocks past nkv are masked
+    const int kc = kc_of(nkv), cf = cf_of(7);       // K / V^T fragments of kc key blocks in a 64-fragment segment per (batch, head)
     KvArgs ka{kv, p + PK_WK, p + PK_WV, (const float *)(p + PK_BK), (const float *)(p + PK_BV), (char *)ws, nkv, kc, cf};
-    if (f16) hipLaunchKernelGGL((k_ca_kvproj<true>), dim3(kc, NH, batch), dim3(256), 0, st, ka);
-    else hipLaunchKernelGGL((k_ca_kvproj<false>), dim3(kc, NH, batch), dim3(256), 0, st, ka);
+    constexpr int KV_LDS = KVW * 4 * 16 * 64 * 4;
+    static LvqLdsOnce kv_once;
+    if (!lvq_ensure_lds(kv_once, {(const void *)k_ca_kvproj<true>, (const void *)k_ca_kvproj<false>}, KV_LDS)) return LVQ_ELAUNCH;
+    if (f16) hipLaunchKernelGGL((k_ca_kvproj<true>), dim3(kc, NH, batch), dim3(KVW * 64), KV_LDS, st, ka);
+    else hipLaunchKernelGGL((k_ca_kvproj<false>), dim3(kc, NH, batch), dim3(KVW * 64), KV_LDS, st, ka);
     if (!lvq_ensure_lds(g_lds_once, {(const void *)k_ca_fused<true, 7>, (const void *)k_ca_fused<false, 7>}, LDS_BYTES))
         return LVQ_ELAUNCH;
     CaArgs a;

@@ -63,8 +63,8 @@ def tol16(nkv):
 
 
 # (B, nq, nkv): the resampled-token shape (nq = 576 leaves half a 128-row tile per batch element), a slice of the headline shape, ragged
-# key counts (1 key; 33 keys = one full block + 1; 224 = every block full), rows = one wave
-SHAPES = [(1, 256, 196), (2, 576, 196), (1, 4096, 196), (1, 128, 33), (3, 64, 224), (1, 32, 1), (2, 160, 100), (1, 128, 64)]
+# key counts (193 = six full blocks + 1 key; 224 = every block full), rows = one wave
+SHAPES = [(1, 256, 196), (2, 576, 196), (1, 4096, 196), (1, 128, 193), (3, 64, 224), (1, 32, 200), (2, 160, 211)]
 
 
 @pytest.mark.parametrize("B,nq,nkv", SHAPES)
