@@ -98,6 +98,7 @@ class VATBlock(_HipModule):
         self.mlp = nn.Sequential(nn.Linear(d_model, d_mlp), nn.GELU(), nn.Dropout(dropout), nn.Linear(d_mlp, d_model),
                                  nn.Dropout(dropout))
         self.d_model, self.n_heads = d_model, n_heads
+        self.fused_ca_in_block = False        # parity-true modes: fp16 fused cross-attention inside forward() too (see forward_tokens)
         if d_model % n_heads or (d_model // n_heads) % 8:
             raise ValueError("head_dim must be a multiple of 8 for the MFMA attention kernels")
 
@@ -218,7 +219,11 @@ class VATBlock(_HipModule):
     def forward_tokens(self, q2: torch.Tensor, kv_bf: Optional[BF], B: int, nq: int, nkv: int, kv_f32: Optional[torch.Tensor] = None) -> torch.Tensor:
         q2 = self._self_attn(q2, B, nq)
         f16 = self._ca_fused_mode(B, nq, nkv) if kv_f32 is not None else None
-        if f16 is not None:
+        # Inside the whole block the 1e-3 budget is shared with the self-attention, the MLP and whatever produced q (VATLiDAR): the fp16
+        # form of the fused kernel (4e-4 on its own) then leaves a 2x margin end to end (5.1e-4 on the bench scene) where the hi + lo
+        # chain leaves 9x (1.05e-4) for < 1 % of a pipeline step -- so a parity-true mode takes it here only when asked
+        # (`fused_ca_in_block`); the plain-bf16 mode, which makes no parity claim, always does
+        if f16 is not None and (not f16 or self.fused_ca_in_block):
             return self._mlp(self._cross_attn_fused(q2, kv_f32, B, nq, f16))
         if kv_bf is None:
             kv_bf = ops.cast(kv_f32.view(B * nkv, self.d_model), self._split())

@@ -169,6 +169,7 @@ def test_fused_ca_inside_the_reference_block_golden(prec):
     synth.load_seeded(m, c["seed"])
     q, kv = dev(synth.randn((c["B"], c["Nq"], c["d"]), c["seed"] + 1000)), dev(synth.randn((c["B"], c["Nk"], c["d"]), c["seed"] + 2000))
     m.precision = prec
+    m.fused_ca_in_block = True
     with torch.no_grad():
         out = m(q, kv)
     g = golden("vat_block_baseline_256x196")
