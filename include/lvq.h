@@ -303,7 +303,19 @@ int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16 *q_lo, con
                                     const int32_t *row_src, const int32_t *pair_src, const int32_t *pair_info, int pair_cap_tiles, const float *totals, int batch, int n_heads, int nq,
                                     int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv,
                                     int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, int k_fp16, lvq_bf16 *o,
-                                    lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream);
+                                    lvq_bf16 *o_lo, int32_t *stats, void *ws, size_t ws_bytes, lvq_stream_t stream);
+
+/* Guard of the plain-bf16 key stream ("mixed" modes), per-model half: g[h * nq + i] = (1 + max_k |scale q_i . k_k|) / sqrt(N_eff)
+ * with N_eff = (sum_k p_k)^2 / sum_k p_k^2, p = softmax weights of query i of head h over the nkv key rows (head_dim 64, nkv % 4 == 0; plain
+ * bf16 operands -- a statistic, not a result).  The error that plain K / V / P leave in the attention output grows like max(g)
+ * (tools/mixed_guard_study.py); the caller keeps the plain stream only while max(g) stays under its threshold and otherwise runs hi + lo
+ * operands.  The per-launch half is lvq_attention_bf16_tiled_signed's `stats` (NULL or four int32 words that are accumulated into: [0] count of
+ * (scene, head, query) rows whose row sum exceeds 1.5x the table's -- the softmax mass moved onto the scene's own keys, which the per-model
+ * statistic has not seen; [1] (batch, head) pairs re-run by the cancellation check; [2] the largest row sum / table row sum seen, as float
+ * bits; [3] unused). */
+size_t lvq_stream_guard_workspace_bytes(int nq, int64_t nkv);
+int lvq_stream_guard(const lvq_bf16 *q, const lvq_bf16 *k_rows, int n_heads, int nq, int64_t nkv, int64_t ldq, int64_t ldk, float scale, float *g,
+                     void *ws, size_t ws_bytes, lvq_stream_t stream);
 
 /* 1 when the long-stream kernel takes (nq, nkv, dh) without bias / mask: head_dim 64, nkv >= 4096 and a multiple of 64, query
  * count with at most 1/8 padding to 128 / 192 rows.  Those are the shapes for which lvq_attention_bf16 accepts the "mixed" operand

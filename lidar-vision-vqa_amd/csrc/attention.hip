@@ -49,6 +49,7 @@ struct AttnArgs {
     int32_t *flags;           // out, per (b, h): the signed result of some query is unusable (non-finite, or cancellation too deep)
     const int32_t *pred;      // in, per (b, h): workgroups / rows of (b, h) with pred == 0 do nothing (the predicated full re-run)
     int force_part;           // write partials even when nsplit == 1
+    int32_t *stats;           // optional [4] (accumulated): rows whose own (dirty) keys dominate the softmax mass | (batch, head) pairs re-run | max l / l_table (float bits) | -
 };
 
 constexpr int KVB = 64;  // keys per tile
@@ -1267,7 +1268,16 @@ __global__ void __launch_bounds__(256) k_attn_combine_signed(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] += w * pr[d0 + r];
     }
-    if (signed_b && d0 == 0 && a.flags && !(l > 0.0625f * lt && l < 3.0e38f)) a.flags[bh] = 1;
+    if (signed_b && d0 == 0 && a.flags && !(l > 0.0625f * lt && l < 3.0e38f)) {
+        a.flags[bh] = 1;
+        if (a.stats && qi == 0) atomicAdd(&a.stats[1], 1);
+    }
+    // per-launch half of the plain-stream guard (lvq_stream_guard is the per-model half): this row's softmax mass sits mostly on the
+    // scene's own (dirty) keys, which the per-model statistic has not seen
+    if (signed_b && d0 == 0 && a.stats && lt > 0.f) {
+        if (l > 1.5f * lt) atomicAdd(&a.stats[0], 1);
+        atomicMax(reinterpret_cast<unsigned int *>(&a.stats[2]), __float_as_uint(fminf(l / lt, 3.0e38f)));      // positive floats order like their bits
+    }
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     float y[4];
 #pragma unroll
@@ -1472,6 +1482,45 @@ __global__ void __launch_bounds__(256) k_softmax_rows(const float *__restrict__ 
     }
 }
 
+// Per-model half of the plain-stream guard: one workgroup per score row s[0 .. n) (raw dot products; softmax weights exp(scale s)):
+//   g = (1 + max |scale s|) / sqrt(N_eff),   N_eff = (sum p)^2 / sum p^2
+// -- the quantity the error of plain bf16 K / V / P on a key stream scales with (tools/mixed_guard_study.py: a per-key 2^-9 rounding
+// moves the output by ~ |score| 2^-9 per unit of softmax mass and averages out over N_eff keys).
+__global__ void __launch_bounds__(256) k_stream_guard_rows(const float *__restrict__ s, int64_t n, float scale, float *__restrict__ g) {
+    __shared__ float red[3][4];
+    const float *sr = s + (int64_t)blockIdx.x * n;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float mx = -INFINITY, amax = 0.f;
+    for (int64_t k = tid * 4; k < n; k += 1024) {
+        const float4 v = *reinterpret_cast<const float4 *>(sr + k);
+        mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o)), amax = fmaxf(amax, __shfl_xor(amax, o));
+    if (lane == 0) red[0][w] = mx, red[1][w] = amax;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])) * scale;
+    amax = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])) * fabsf(scale);
+    __syncthreads();
+    float l1 = 0.f, l2 = 0.f;
+    for (int64_t k = tid * 4; k < n; k += 1024) {
+        const float4 v = *reinterpret_cast<const float4 *>(sr + k);
+        const float p0 = expf(v.x * scale - mx), p1 = expf(v.y * scale - mx), p2 = expf(v.z * scale - mx), p3 = expf(v.w * scale - mx);
+        l1 += (p0 + p1) + (p2 + p3);
+        l2 += (p0 * p0 + p1 * p1) + (p2 * p2 + p3 * p3);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) l1 += __shfl_xor(l1, o), l2 += __shfl_xor(l2, o);
+    if (lane == 0) red[0][w] = l1, red[1][w] = l2;
+    __syncthreads();
+    if (tid == 0) {
+        l1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        l2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        g[blockIdx.x] = (1.0f + amax) * sqrtf(l2) / l1;
+    }
+}
+
 // [rows, cols] (ld) bf16 -> transposed [cols, rows_pad] bf16, zero padded (V^T for the split path)
 __global__ void __launch_bounds__(256) k_transpose_bf16(const uint16_t *__restrict__ x, int rows, int cols, int64_t ld,
                                                         int rows_pad, uint16_t *__restrict__ y) {
@@ -1666,7 +1715,7 @@ extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16
                                                const int32_t *pair_info, int pair_cap_tiles, const float *totals, int batch, int n_heads, int nq,
                                                int n_tiles, int dh, int64_t q_bstride, int64_t ldq, int64_t q_hstride, int64_t ldkv,
                                                int64_t kv_hstride, int64_t o_bstride, int64_t ldo, int64_t o_hstride, float scale, int k_fp16,
-                                               lvq_bf16 *o, lvq_bf16 *o_lo, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+                                               lvq_bf16 *o, lvq_bf16 *o_lo, int32_t *stats, void *ws, size_t ws_bytes, lvq_stream_t stream) {
     if (batch <= 0 || n_heads <= 0 || nq < 0 || n_tiles <= 0 || pair_cap_tiles <= 0 || !q || !k_rows || !v_rows || !row_src || !pair_src ||
         !pair_info || !totals || !o)
         return LVQ_EINVAL;
@@ -1704,10 +1753,11 @@ extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16
     const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
     if (hipMemsetAsync(flags, 0, (size_t)batch * n_heads * sizeof(int32_t), st) != hipSuccess) return LVQ_ELAUNCH;
     a.flags = flags;
+    a.stats = stats;
     launch_k32<2>(a, pl.k32, qs, nwg, lds, st);
     hipLaunchKernelGGL(k_attn_combine_signed, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
     // predicated full re-run of the flagged (batch, head) pairs: every workgroup of an unflagged pair returns at once
-    a.flags = nullptr; a.pred = flags; a.pair_src = nullptr; a.pair_info = nullptr; a.totals = nullptr;
+    a.flags = nullptr; a.stats = nullptr; a.pred = flags; a.pair_src = nullptr; a.pair_info = nullptr; a.totals = nullptr;
     launch_k32<1>(a, pl.k32, qs, nwg, lds, st);
     hipLaunchKernelGGL(k_attn_combine_signed, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
     return lvq_launch_status();
@@ -1814,6 +1864,26 @@ extern "C" int lvq_attention_bf16(const lvq_bf16 *q, const lvq_bf16 *q_lo, const
                            (int64_t)nq * nkp, (int64_t)dh * nkp, o_hstride, nullptr, o + b * o_bstride,
                            o_lo ? o_lo + b * o_bstride : nullptr, stream);
         if (rc != LVQ_OK) return rc;
+    }
+    return lvq_launch_status();
+}
+
+extern "C" size_t lvq_stream_guard_workspace_bytes(int nq, int64_t nkv) { return (size_t)nq * (size_t)nkv * sizeof(float) + 256; }
+
+// g[h * nq + i] = (1 + max_k |scale q_i . k_k|) / sqrt(N_eff) of head h, query i over the nkv keys (head_dim 64, nkv % 4 == 0, plain bf16
+// operands: a guard statistic, not a result).  The caller reduces g (its maximum) and decides the route.
+extern "C" int lvq_stream_guard(const lvq_bf16 *q, const lvq_bf16 *k_rows, int n_heads, int nq, int64_t nkv, int64_t ldq, int64_t ldk, float scale,
+                                float *g, void *ws, size_t ws_bytes, lvq_stream_t stream) {
+    if (!q || !k_rows || !g || !ws || n_heads <= 0 || nq <= 0 || nkv <= 0) return LVQ_EINVAL;
+    if ((nkv & 3) || nkv > 0x7fffffff) return LVQ_EUNSUPPORTED;
+    if (ws_bytes < lvq_stream_guard_workspace_bytes(nq, nkv)) return LVQ_EWORKSPACE;
+    float *S = (float *)ws;
+    hipStream_t st = lvq_s(stream);
+    for (int h = 0; h < n_heads; ++h) {
+        const int rc = lvq_gemm_bf16(q + (int64_t)h * 64, nullptr, k_rows + (int64_t)h * 64, nullptr, nullptr, nullptr, nullptr, 0, 1.0f, 0, nq, (int)nkv, 64,
+                                     ldq, ldk, nkv, 1, 0, 0, 0, S, nullptr, nullptr, stream);
+        if (rc != LVQ_OK) return rc;
+        hipLaunchKernelGGL(k_stream_guard_rows, dim3((unsigned)nq), dim3(256), 0, st, S, nkv, scale, g + (int64_t)h * nq);
     }
     return lvq_launch_status();
 }

@@ -428,7 +428,7 @@ def bev_scene_pairs(row_src: torch.Tensor, batch: int, n_tiles: int, row_base: i
 
 
 def attention_tiled_signed(q: BF, kv: torch.Tensor, row_src: torch.Tensor, pair_src: torch.Tensor, pair_info: torch.Tensor, totals: torch.Tensor, *, batch: int, n_heads: int, nq: int, n_tiles: int, dh: int, scale: float,
-                           shared_q: bool, tag: Optional[str] = None, k_fp16: bool = False) -> BF:
+                           shared_q: bool, tag: Optional[str] = None, k_fp16: bool = False, stats: Optional[torch.Tensor] = None) -> BF:
     """attention_tiled over the dirty rows only (queries independent of the batch; `totals` from attention_stream_totals with the
     SAME q over the table rows kv[:n_tiles*64]).  q BF [nq, d] when shared_q else [batch*nq, d] (identical per batch) -> BF [batch*nq, d]."""
     qh, ql = q
@@ -444,9 +444,27 @@ def attention_tiled_signed(q: BF, kv: torch.Tensor, row_src: torch.Tensor, pair_
         rc = L.lvq_attention_bf16_tiled_signed(F.ptr(qh), F.ptr(ql), F.ptr(kv), F.ptr(kv[:, d:]), F.ptr(row_src), F.ptr(pair_src), F.ptr(pair_info), F.cint(pair_src.shape[1]), F.ptr(totals),
                                                F.cint(batch), F.cint(n_heads), F.cint(nq), F.cint(n_tiles), F.cint(dh),
                                                F.i64(0 if shared_q else nq * d), F.i64(d), F.i64(dh), F.i64(2 * d), F.i64(dh), F.i64(nq * d), F.i64(d),
-                                               F.i64(dh), F.cfloat(scale), F.cint(1 if k_fp16 else 0), F.ptr(oh), F.ptr(ol), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
+                                               F.i64(dh), F.cfloat(scale), F.cint(1 if k_fp16 else 0), F.ptr(oh), F.ptr(ol), F.ptr(stats), F.ptr(ws), F.csize(ws.numel()), F.stream_ptr(dev))
     F.check(rc, f"lvq_attention_bf16_tiled_signed (B={batch}, H={n_heads}, nq={nq}, tiles={n_tiles})")
     return oh, ol
+
+
+def stream_guard(q_hi: torch.Tensor, k_rows: torch.Tensor, n_heads: int, scale: float) -> torch.Tensor:
+    """Per-model half of the plain-stream guard (include/lvq.h: lvq_stream_guard): q_hi [nq, n_heads * 64] bf16, k_rows [nkv, >= n_heads * 64]
+    bf16 (row stride = k_rows.stride(0)) -> g [n_heads, nq] fp32, g = (1 + max |score|) / sqrt(N_eff) per (head, query)."""
+    F.require_cuda(q_hi)
+    assert q_hi.dtype == torch.bfloat16 and k_rows.dtype == torch.bfloat16 and k_rows.stride(1) == 1 and k_rows.is_cuda
+    nq, nkv = q_hi.shape[0], k_rows.shape[0]
+    dev = q_hi.device
+    L = F.lib()
+    L.lvq_stream_guard_workspace_bytes.restype = F.csize
+    nbytes = int(L.lvq_stream_guard_workspace_bytes(F.cint(nq), F.i64(nkv)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)          # once per weights version: not cached
+    g = torch.empty((n_heads, nq), dtype=torch.float32, device=dev)
+    rc = L.lvq_stream_guard(F.ptr(q_hi), F.ptr(k_rows), F.cint(n_heads), F.cint(nq), F.i64(nkv), F.i64(q_hi.stride(0)), F.i64(k_rows.stride(0)),
+                            F.cfloat(scale), F.ptr(g), F.ptr(ws), F.csize(nbytes), F.stream_ptr(dev))
+    F.check(rc, "lvq_stream_guard")
+    return g
 
 
 def scale_add_rows(x: torch.Tensor, add: Optional[torch.Tensor], alpha: float = 1.0) -> torch.Tensor:

@@ -469,10 +469,11 @@ def test_attention_tiled_signed_fp16_qk():
     assert float((o.to_f32(full) - g32).abs().max()) < 2e-5 * max(float(r32.abs().max()), 1.0)
 
 
-@pytest.mark.parametrize("prec,tol", [("mixed", 2e-3), ("mixed16", 3e-3), ("bf16", None)])
+@pytest.mark.parametrize("prec,tol", [("mixed", 1e-3), ("mixed16", 1e-3), ("bf16", None)])
 def test_tiled_route_vs_oracle(prec, tol):
-    """Small-grid pipeline through the tiled route against the CPU oracle.  16 384 keys average the per-key roundings 4x less
-    than the 262 144 of the bench workload, hence 2e-3 here; the full-size run (test_gpu_pipeline) holds the north-star 1e-3."""
+    """Small-grid pipeline through the tiled route against the CPU oracle at the north-star 1e-3.  16 384 keys average the per-key
+    roundings 4x less than the 262 144 of the bench workload: the stream guard (VATLiDAR.stream_guard) decides per model whether the
+    plain key stream is still good for the bar and runs hi + lo operands otherwise (tests/test_gpu_mixed_guard.py)."""
     cfg = tiled_cfg(dist="C")
     pipe = P.FusionPipeline(cfg, DEV, precision=prec)
     pts, off, patches, pts_np, patches_np = P.synthetic_batch(cfg, 2, 1001, DEV)
