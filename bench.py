@@ -10,13 +10,18 @@ Workload = BASELINE.json configs[1]: 32 768-point Dist-C scene
 d = 768, 12 heads, bf16 MFMA.  Scenes shard one batch per rank with no data-path collective; the only exchange is one RCCL
 all-reduce(SUM) per step of a fused fp32 buffer [token-sum (d) | scene count] -> "scaling": "weak".
 
+`--workload cfg4` / `cfg5` run BASELINE configs[3] / configs[4] instead (120 000-point scenes with max_voxels = 160 000; the token-level
+VQA-head workload 256 LiDAR x 576 image x 32 answer tokens), both with the stand-in language head attached and the all-reduced buffer
+[loss | n_scenes | answer-logit sums]; the default (cfg2) is the configuration the metric is quoted on.
+
 `value` is measured in the precision mode `--precision` (default "mixed": bf16 MFMA tiles everywhere, plain bf16 operands on the
 262 144-key K/V stream, hi + lo bf16 operands elsewhere -- the fastest mode that meets the north-star 1e-3 tolerance, see
-`parity_vs_cpu`, which is measured for EVERY mode timed in this run against the CPU oracle).  Rank 0 prints ONE JSON line with
-`roofline` (dominant kernel: the stream attention or the K|V projection GEMM, whichever took longer; algorithmic FLOPs / HIP-event time on the launch stream inside the timed
-region), `roofline_headline` (the literal "32k pts x 196 patches" cross-attention sub-path), every cross-attention row of
-SURVEY 8d, the HBM-bound voxelisers at cfg-3, the same workload on Dist-U scenes, and `cpu_baseline` (the CPU restatement in
-oracle/ timed on the host cores on a bounded sample).
+`parity_vs_cpu`, which is measured for EVERY mode timed in this run against the CPU oracle on three scenes).  Rank 0 prints ONE JSON line
+with `roofline` = the cross-attention kernel at the metric's own shape "32k pts x 196 patches" (lvq_ca_fused at (1, 32768, 196, 768, 12):
+SURVEY 8d's algorithmic FLOPs / HIP-event time of its launches on the launch stream), `roofline_attention` = the dominant kernel of the
+step (VATLiDAR's cross-attention over the BEV key stream; three readings of its FLOPs), `roofline_bev_kv`, every cross-attention row of
+SURVEY 8d, the HBM-bound voxelisers at cfg-3, the same workload on Dist-U scenes and at the reference's default depth, and `cpu_baseline`
+(the CPU restatement in oracle/ timed on the host cores on a bounded sample, thread count chosen by a sweep).
 """
 from __future__ import annotations
 
@@ -175,6 +180,33 @@ def cpu_voxel_baseline(scenes):
             "sample": "cfg-3, 8 x 65 536 points, 0.1 m grid, T=10, 160 000 voxels: median of 5 after warm-up"}
 
 
+class HeadStage:
+    """BASELINE configs[3] / configs[4]: the stand-in language head behind the fused tokens.  Prefix assembly
+    as validation.py:125-148 (vision prefix, LiDAR prefix, prompt, 32 answer positions), Qwen2-architecture decoder of the fused width
+    (random weights: the reference's Qwen checkpoint is fetched by name), loss + the logits of the 32 answer positions."""
+
+    def __init__(self, d, dev, precision, n_prompt=12, n_answer=32, vocab=8192, n_layers=4, seed=85):
+        from lidar_vision_vqa_amd import head as HD, synth
+        self.hd = HD
+        self.model = HD.StandInHead(vocab, d, 4 * d, d // 64, 2, n_layers).to(dev).eval()
+        synth.load_seeded(self.model, seed)
+        self.model.precision = "bf16x3" if precision in ("mixed", "mixed16") else precision
+        g = torch.Generator().manual_seed(seed)
+        self.n_answer, self.vocab = n_answer, vocab
+        self.ids = (torch.randint(4, vocab, (1, n_prompt + n_answer), generator=g)).to(dev)
+        self.special = self.model.embed(torch.arange(4, device=dev).view(1, 4))[0]
+        self.n_prompt = n_prompt
+
+    def __call__(self, prefix_vision, prefix_lidar):
+        B = prefix_lidar.shape[0]
+        ids = self.ids.expand(B, -1)
+        emb = self.model.embed(ids)
+        e_prompt, e_answer = emb[:, :self.n_prompt].contiguous(), emb[:, self.n_prompt:].contiguous()
+        inp, attn, labels = self.hd.assemble_prefix(prefix_vision, prefix_lidar, self.special, e_prompt, e_answer, ids[:, self.n_prompt:].contiguous())
+        out = self.model(inp, attn, labels)
+        return out.loss, out.logits[:, -self.n_answer:]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +214,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scenes", type=int, default=32, help="scenes per GPU per step")
     ap.add_argument("--precision", default="mixed", choices=list(MODES))
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg4", "cfg5"], help="BASELINE configs[1] (default, the metric's own), [3] or [4]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other modes, cross-attention rows, voxelisers, Dist-U)")
     args = ap.parse_args()
@@ -203,20 +236,55 @@ def main():
     torch.set_grad_enabled(False)      # inference path (the reference's eval / no_grad mode)
 
     from lidar_vision_vqa_amd import dist as D
-    from lidar_vision_vqa_amd import fusion, ops, pipeline as P
+    from lidar_vision_vqa_amd import fusion, ops, pipeline as P, synth
 
     D.init_dist_if_needed("gloo" if rehearsal else None)
-    cfg = P.PipelineConfig()
-    pipe = P.FusionPipeline(cfg, dev, precision=args.precision)
+    wl = args.workload
+    cfg = P.PipelineConfig() if wl != "cfg4" else P.PipelineConfig(n_points=120000, max_voxels_3d=160000)
     S = args.scenes
-    # scene i of rank r: seed 1100 + 1000*r + i (SURVEY 8d cfg-4 convention)
-    pts, off, patches, pts_np, patches_np = P.synthetic_batch(cfg, S, 1100 + 1000 * rank, dev)
-    red = torch.zeros(cfg.d_model + 1, dtype=torch.float32, device=dev)
+    head = None
+    if wl == "cfg5":
+        # token level: LiDAR tokens [S, 256, d] and image tokens [S, 576, d] resident in HBM -> VATBlock(q = LiDAR, kv = image) -> head
+        pipe = None
+        fuse = fusion.VATBlock(cfg.d_model, cfg.n_heads, 4 * cfg.d_model, 0.1).to(dev).eval()
+        synth.load_seeded(fuse, cfg.weight_seed + 2)
+        fuse.precision = args.precision
+        lt = torch.from_numpy(np.stack([synth.randn((256, cfg.d_model), 5100 + 1000 * rank + i) for i in range(S)])).to(dev)
+        im = torch.from_numpy(np.stack([synth.image_patches(576, cfg.d_model, 7100 + 1000 * rank + i) for i in range(S)])).to(dev)
+        tokens_per_scene = 256 + 576
+        workload = ("BASELINE configs[4]: 256 LiDAR tokens x 576 image tokens (d=768, 12 heads) -> VATBlock(q = LiDAR tokens, kv = image tokens) -> "
+                    "prefix assembly (vision 576 | LiDAR 256 | prompt 12 | 32 answer positions: L = 880) -> stand-in Qwen2-architecture head "
+                    "(d=768, 12/2 heads, 4 layers, vocab 8192) -> loss + answer logits")
+    else:
+        pipe = P.FusionPipeline(cfg, dev, precision=args.precision)
+        # scene i of rank r: seed 1100 + 1000*r + i (SURVEY 8d cfg-4 convention)
+        pts, off, patches, pts_np, patches_np = P.synthetic_batch(cfg, S, 1100 + 1000 * rank, dev)
+        tokens_per_scene = cfg.n_queries
+        workload = ("BASELINE configs[1]: " if wl == "cfg2" else "BASELINE configs[3] (120 000 points / scene, max_voxels 160 000, head attached): ") + cfg.describe()
+    if wl in ("cfg4", "cfg5"):
+        head = HeadStage(cfg.d_model, dev, args.precision)
+        red = torch.zeros(2 + head.n_answer * head.vocab, dtype=torch.float32, device=dev)     # [loss sum | n_scenes | answer-logit sums]
+    else:
+        red = torch.zeros(cfg.d_model + 1, dtype=torch.float32, device=dev)
 
     def step():
-        out = pipe(pts, off, patches)
-        D.reduce_step(out["fused"], red)       # fused [token-sum | n_scenes] buffer, one all-reduce when world > 1
-        return out
+        if wl == "cfg2":
+            out = pipe(pts, off, patches)
+            D.reduce_step(out["fused"], red)       # fused [token-sum | n_scenes] buffer, one all-reduce when world > 1
+            return out
+        if wl == "cfg4":
+            fused = pipe(pts, off, patches)["fused"]
+            loss, logits = head(patches, fused)
+        else:
+            fused = fuse(lt, im)
+            loss, logits = head(im, fused)
+        # one fused buffer [loss * S | S | sum over scenes of the 32 x V answer logits], one all-reduce
+        red[0:1] = loss * float(S)
+        red[1:2].fill_(float(S))
+        red[2:] = logits.sum(0).reshape(-1)
+        if D.is_dist():
+            torch.distributed.all_reduce(red, op=torch.distributed.ReduceOp.SUM)
+        return fused
 
     ops.EVENTS = {}                 # event recording is on during warm-up too (first-use costs stay out of the timed region)
     for _ in range(args.warmup):
@@ -238,7 +306,7 @@ def main():
     dt = time.perf_counter() - t0
     events, ops.EVENTS = ops.EVENTS, None
     dt = D.max_over_ranks(dt, dev)
-    tokens_per_step = S * cfg.n_queries
+    tokens_per_step = S * tokens_per_scene
     value = world * tokens_per_step * args.steps / dt
 
     if rank != 0:
@@ -246,108 +314,116 @@ def main():
         D.finalize()
         return
 
-    # ---- roofline of the two big kernels of VATLiDAR's cross-attention; `roofline` is whichever took longer per launch ----
-    h, w = cfg.bev_hw
-    d = cfg.d_model
-    per_step = cfg.n_layers + 1        # launches per step: n_layers (VATLiDAR, the S*HW-key stream) + 1 (fusion block, 196 keys); keep the big ones
-    big = lambda tag: [p for i, p in enumerate(events.get(tag, [])) if (i % per_step) < cfg.n_layers]
-    kv_ms, at_ms = avg_ms(big("ca_kv_proj")), avg_ms(big("ca_attn"))
-    # rows the GEMM actually projects: the tiled key stream computes K|V for the DIRTY cells only (a pillar in the 3 x 3 neighbourhood; clean
-    # cells come from the per-model table) -> EXECUTED rows, read back once after the timed region; the dense routes project every BEV cell
-    tc = getattr(pipe.vat_lidar, "_last_tile_counts", None)
-    live_rows = int(tc[2]) if tc is not None else S * h * w
-    kv_rows = (live_rows + 255) // 256 * 256             # whole 256-row tiles run
-    kv_flops = 2.0 * kv_rows * (2 * d) * d               # 4 d^2 per projected key
-    at_flops = 4.0 * S * cfg.n_queries * (h * w) * d     # QK^T + PV over EVERY key (4 nq nkv d per scene)
     prec = args.precision
-    roofline = roofline_kv = roofline_attn = None
-    if kv_ms:
-        ach = kv_flops / (kv_ms * 1e-3) / 1e12
-        form = {"bf16": "plain operands: 1 MFMA pass", "mixed": "A plain, W hi+lo: 2 MFMA passes (executed FLOPs = 2x algorithmic)",
-                "mixed16": "A plain, W hi+lo: 2 MFMA passes (executed FLOPs = 2x algorithmic)",
-                "bf16x3": "A and W hi+lo: 3 MFMA passes (executed FLOPs = 3x algorithmic)"}[prec]
-        ex = {"bf16": 1, "mixed": 2, "mixed16": 2, "bf16x3": 3}[prec]
-        tr, src = profile_traffic([f"k_gemm_256 M={kv_rows} N={2 * d} K={d} {prec}"])
-        roofline_kv = {"bound": "mfma", "kernel": "k_gemm_256 (256x256 tile, LDS-DMA, A ring 3 / W ring 2; VATLiDAR.ca K|V projection over the dirty BEV cells, "
-                       f"M = {kv_rows} of {S * h * w} BEV cells, N=2d, K=d); " + form,
-                       # achieved / frac / flops_per_launch = EXECUTED MFMA FLOPs (rows actually projected x passes actually issued)
-                       "achieved": round(ach * ex, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach * ex / PEAK_BF16_TFLOPS, 4),
-                       "traffic": tr, "traffic_source": src, "avg_launch_ms": round(kv_ms, 4), "flops_per_launch": kv_flops * ex,
-                       "rows_projected": kv_rows, "rows_dense": S * h * w, "live_fraction": round(live_rows / float(S * h * w), 4),
-                       "mfma_passes": ex, "achieved_one_pass": round(ach, 2),
-                       "dense_formula_flops": 2.0 * S * h * w * (2 * d) * d,
-                       "dense_formula_rate": round(2.0 * S * h * w * (2 * d) * d / (kv_ms * 1e-3) / 1e12, 2)}
-    if at_ms:
-        ach = at_flops / (at_ms * 1e-3) / 1e12
-        form = {"bf16": "Q, K, P, V plain: 1 MFMA pass", "mixed": "Q hi+lo (2 MFMA passes over QK^T), K, P, V plain: executed FLOPs = 1.5x algorithmic",
-                "mixed16": "Q one fp16 operand against fp16 K (1 MFMA pass over QK^T), P, V plain bf16",
-                "bf16x3": "all operands hi+lo: executed FLOPs = 3x algorithmic"}[prec]
-        ex = {"bf16": 1.0, "mixed": 1.5, "mixed16": 1.0, "bf16x3": 3.0}[prec]
-        # keys the launch actually streams: block 0's queries are scene-independent, so a scene streams only its dirty cells, twice
-        # (computed rows added, the table rows of the same cells subtracted from the per-model totals) -- read back after the timed region
-        pi = getattr(pipe.vat_lidar.blocks[0], "_last_pair_info", None)
-        keys_streamed = S * h * w
-        if pi is not None:
-            pin = pi.cpu().numpy()
-            keys_streamed = int(sum(int(t) * 64 if int(u) else h * w for t, u in pin))
-            form += f"; signed pair stream: {keys_streamed} of {S * h * w} keys streamed ({sum(int(u) for _, u in pin)} of {S} scenes signed)"
-        ex *= keys_streamed / float(S * h * w)
-        piped = (prec in ("mixed", "mixed16") or os.environ.get("LVQ_ATTN_PIPE")) and not os.environ.get("LVQ_ATTN_NO_PIPE")
-        ring = ("software-pipelined stream (next block's score MFMAs between this block's exponentials), LDS-DMA ring of 4 K|V tiles, 2 waves per SIMD"
-                if piped else "LDS-DMA ring of 3 K|V tiles, 3 waves per SIMD")
-        tr, src = profile_traffic([f"k_attn32 S={S} nq={cfg.n_queries} nkv={h * w} {prec}"])
-        roofline_attn = {"bound": "mfma", "kernel": f"k_attn32 (VATLiDAR.ca: {S} scenes x {cfg.n_heads} heads x {cfg.n_queries} queries over the {h * w}-key "
-                         "BEV stream, head_dim 64; 32x32x16 MFMA, " + ring + ", fixed softmax reference); " + form,
-                         # achieved / frac / flops_per_launch = EXECUTED MFMA FLOPs (keys actually streamed x passes actually issued);
-                         # the dense formula of SURVEY 8d (every key of every scene) is reported beside it, not as the roofline number
-                         "achieved": round(ach * ex, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach * ex / PEAK_BF16_TFLOPS, 4),
-                         "traffic": tr, "traffic_source": src, "avg_launch_ms": round(at_ms, 4), "flops_per_launch": at_flops * ex,
-                         "keys_streamed": keys_streamed, "keys_dense": S * h * w,
-                         "dense_formula_flops": at_flops, "dense_formula_rate": round(ach, 2), "dense_formula_frac": round(ach / PEAK_BF16_TFLOPS, 4)}
-    # the fused K|V kernel (default route): refine conv + folded LayerNorm / K|V projection for the dirty cells, HBM-side kernel
-    roofline_bev_kv = None
-    bk_ms = avg_ms(events.get("bev_kv", []))
-    if bk_ms:
-        # K|V rows out (bf16) + the table T once (fp32) + index map + the (t hi, t lo, rstd, key) rows written and read between the two launches
-        nbytes = live_rows * (2 * 2 * d) + (h * w) * (2 * d) * 4 + S * h * w * 4 + 2 * live_rows * (256 + 8)
-        ex_flops = 2.0 * live_rows * (2 * d + 64) * 64 * {"bf16": 1, "mixed": 3, "mixed16": 3, "bf16x3": 3}[prec]
-        tr, src = profile_traffic([f"k_tile_kv S={S} {prec}"])
-        roofline_bev_kv = {"bound": "hbm", "kernel": "lvq_bev_tile_kv = k_conv_rows + k_kv_rows (pillar halo gather + depthwise 3x3 + GELU -> 64-channel token t -> K|V = rstd (M t + m0) + T[key] "
-                           f"for the {live_rows} dirty cells of {S * h * w}; LayerNorm and the 768-deep K|V projection folded into a 64-deep one)",
-                           "achieved": round(nbytes / (bk_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": round(nbytes / (bk_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": nbytes, "traffic": tr, "traffic_source": src,
-                           "avg_launch_ms": round(bk_ms, 4), "rows": live_rows, "rows_dense": S * h * w,
-                           "mfma_flops_executed": ex_flops, "mfma_rate": round(ex_flops / (bk_ms * 1e-3) / 1e12, 1),
-                           "replaces": "token kernel + K|V GEMM over the dirty rows (4 d^2 FLOPs per key, SURVEY 8d): 4.1 + 10.0 ms at the same row count"}
-    if roofline_kv or roofline_attn:
-        roofline = roofline_attn if (at_ms or 0) >= (kv_ms or 0) else roofline_kv
-
     result = {
         "metric": "fused tokens/sec/GPU + cross-attn MFMA-roofline % (32k pts x 196 patches)",
         "value": round(value, 1), "unit": "fused tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1]: " + cfg.describe(), "scenes_per_gpu_per_step": S,
-                   "fused_tokens_per_scene": cfg.n_queries, "parallelism": f"scene-parallel x{world}" + (f" (REHEARSAL: {world} ranks on {ndev} device(s), gloo)" if rehearsal else ""),
-                   "precision_mode": args.precision + " (bf16 MFMA tiles throughout; see parity_vs_cpu for the error of every mode)"},
-        "roofline": roofline, "roofline_kv_proj": roofline_kv, "roofline_bev_kv": roofline_bev_kv, "roofline_attention": roofline_attn,
+        "config": {"workload": workload, "scenes_per_gpu_per_step": S, "fused_tokens_per_scene": tokens_per_scene,
+                   "parallelism": f"scene-parallel x{world}" + (f" (REHEARSAL: {world} ranks on {ndev} device(s), gloo)" if rehearsal else ""),
+                   "precision_mode": prec + " (bf16 / fp16 MFMA tiles throughout; see parity_vs_cpu for the error of every mode)"},
     }
 
-    mode_values = {args.precision: round(value, 1)}
-    if not args.no_extras and world == 1:                 # secondary measurements: single-GPU runs only (N > 1 prints the scaling line and leaves)
+    # ---- `roofline`: the cross-attention kernel at the metric's own shape (B, Nq, Nkv, d, h) = (1, 32768, 196, 768, 12), SURVEY 8d row 1 ----
+    d, h = 768, 12
+    blk = fusion.VATBlock(d, h, 4 * d, 0.1).to(dev).eval()
+    synth.load_seeded(blk, 401)
+    blk.precision = prec
+    qh, kvh = torch.randn(1, 32768, d, device=dev), torch.randn(1, 196, d, device=dev)
+    for _ in range(5):
+        blk.cross_attention(qh, kvh)
+    ops.EVENTS = {}
+    for _ in range(20):
+        blk.cross_attention(qh, kvh)
+    torch.cuda.synchronize()
+    ev_h, ops.EVENTS = ops.EVENTS, None
+    flops_h = 4.0 * 32768 * d * d + 4.0 * 196 * d * d + 4.0 * 32768 * 196 * d          # SURVEY 8d F_ca: 97.5 GFLOP
+    fused_route = "ca_fused" in ev_h
+    if fused_route:
+        ms_h = avg_ms(ev_h["ca_fused"])
+        # executed MFMA FLOPs: the 196 keys run as 7 blocks of 32 (224 key slots) in both attention products and in the K|V projection
+        flops_ex = 4.0 * 32768 * d * d + 4.0 * 224 * d * d + 4.0 * 32768 * 224 * d
+        tr, src = profile_traffic([f"lvq_ca_fused 1x32768x196 {prec}"])
+        kern = ("lvq_ca_fused = k_ca_kvproj + k_ca_fused (csrc/cross_fused.hip): LayerNorm, Q projection, softmax(Q K^T) V, out projection, bias and fp32 "
+                "residual of `q + ca(ca_ln(q), kv, kv)` in one kernel, " + ("IEEE fp16" if prec != "bf16" else "bf16") + " MFMA operands (32x32x16), fp32 accumulation; "
+                "HIP events around the two launches on the launch stream, 20 launches")
+    else:                                                       # bf16x3: the unfused hi + lo chain (5 launches)
+        ms_h = event_ms(lambda: blk.cross_attention(qh, kvh), iters=10)
+        flops_ex, tr, src = flops_h * 3.0, None, None
+        kern = "unfused chain (LayerNorm, Q / K|V / out projections, attention): hi + lo operands, three MFMA passes; whole sub-path"
+    ach = flops_h / (ms_h * 1e-3) / 1e12
+    result["roofline"] = {
+        "bound": "mfma", "kernel": kern, "shape": [1, 32768, 196, d, h], "mode": prec,
+        "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+        "frac_algorithmic": round(ach / PEAK_BF16_TFLOPS, 4), "frac_executed": round(flops_ex / (ms_h * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "flops_per_launch": flops_h, "flops_executed": flops_ex, "avg_launch_ms": round(ms_h, 4),
+        "algorithmic_bytes": 2.0 * 32768 * d * 4 + 196 * d * 4 + 4.0 * d * d * 2, "traffic": tr, "traffic_source": src,
+        "hbm_floor_ms": round((2.0 * 32768 * d * 4) / (PEAK_HBM_GBS * 1e9) * 1e3, 4), "mfma_floor_ms": round(flops_h / (PEAK_BF16_TFLOPS * 1e12) * 1e3, 4)}
+    del qh, kvh
+
+    # ---- `roofline_attention`: the dominant kernel of the step (cfg2 / cfg4): VATLiDAR's cross-attention over the BEV key stream ----
+    if pipe is not None:
+        hh, ww = cfg.bev_hw
+        per_step = cfg.n_layers + (0 if "ca_fused" in events else 1)   # attention launches per step: VATLiDAR layers (+ the fusion block's, if unfused)
+        at_pairs = [p for i, p in enumerate(events.get("ca_attn", [])) if (i % per_step) < cfg.n_layers]
+        at_ms = avg_ms(at_pairs)
+        tc = getattr(pipe.vat_lidar, "_last_tile_counts", None)
+        live_rows = int(tc[2]) if tc is not None else S * hh * ww
+        if at_ms:
+            dense = 4.0 * S * cfg.n_queries * (hh * ww) * d          # QK^T + PV over EVERY key (4 nq nkv d per scene)
+            passes = {"bf16": 1.0, "mixed": 1.5, "mixed16": 1.0, "bf16x3": 3.0}[prec]
+            pi = getattr(pipe.vat_lidar.blocks[0], "_last_pair_info", None)
+            keys_streamed = S * hh * ww
+            note = ""
+            if pi is not None:
+                pin = pi.cpu().numpy()
+                keys_streamed = int(sum(int(t) * 64 if int(u) else hh * ww for t, u in pin))
+                note = f"; signed pair stream: {keys_streamed} of {S * hh * ww} key slots streamed ({sum(int(u) for _, u in pin)} of {S} scenes signed)"
+            streamed = 4.0 * cfg.n_queries * keys_streamed * d
+            tr, src = profile_traffic([f"k_attn32 S={S} nq={cfg.n_queries} nkv={hh * ww} {prec}"])
+            rate = lambda f: round(f / (at_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+            result["roofline_attention"] = {
+                "bound": "mfma", "kernel": f"k_attn32 (VATLiDAR.ca: {S} scenes x {cfg.n_heads} heads x {cfg.n_queries} queries over the {hh * ww}-key BEV stream, head_dim 64; "
+                "32x32x16 MFMA, LDS-DMA ring, fixed softmax reference)" + note,
+                # three readings, as VERDICT r2 asks: MFMA passes actually issued over the key slots actually streamed | one pass over the streamed
+                # key slots (no hi + lo inflation; a dirty cell still counts twice: computed row + subtracted table row) | SURVEY 8d's dense formula
+                "frac_executed": rate(streamed * passes), "frac_algorithmic_streamed": rate(streamed), "frac_dense_formula": rate(dense),
+                "frac": rate(streamed * passes), "achieved": round(streamed * passes / (at_ms * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "avg_launch_ms": round(at_ms, 4), "flops_executed": streamed * passes, "keys_streamed": keys_streamed, "keys_dense": S * hh * ww,
+                "traffic": tr, "traffic_source": src}
+        bk_ms = avg_ms(events.get("bev_kv", []))
+        if bk_ms:
+            # K|V rows out (bf16) + the table T once (fp32) + index map + the (t hi, t lo, rstd, key) rows written and read between the two launches
+            nbytes = live_rows * (2 * 2 * d) + (hh * ww) * (2 * d) * 4 + S * hh * ww * 4 + 2 * live_rows * (256 + 8)
+            tr, src = profile_traffic([f"k_tile_kv S={S} {prec}"])
+            result["roofline_bev_kv"] = {"bound": "hbm", "kernel": "lvq_bev_tile_kv = k_conv_rows + k_kv_rows (pillar halo gather + depthwise 3x3 + GELU -> 64-channel token t -> "
+                                         f"K|V = rstd (M t + m0) + T[key] for the {live_rows} dirty cells of {S * hh * ww})",
+                                         "achieved": round(nbytes / (bk_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                         "frac": round(nbytes / (bk_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": nbytes, "traffic": tr, "traffic_source": src,
+                                         "avg_launch_ms": round(bk_ms, 4), "rows": live_rows, "rows_dense": S * hh * ww}
+        g_model = pipe.vat_lidar._pe_cache.get(("stream_guard", hh, ww, dev))
+        result["stream_guard"] = {"statistic_table_keys": None if g_model is None else round(g_model[1], 4), "threshold": pipe.vat_lidar.STREAM_GUARD_MAX,
+                                  "tripped": getattr(pipe.vat_lidar, "_guard_tripped", None) is not None,
+                                  "note": "max over (head, query) of (1 + max |score|) / sqrt(N_eff): the mixed modes keep the plain bf16 key stream only below the "
+                                          "threshold (model statistic once per weights version + audits of the scenes' own key streams), else hi + lo operands"}
+
+    mode_values = {prec: round(value, 1)}
+    vscenes = None
+    if not args.no_extras and world == 1 and wl == "cfg2":     # secondary measurements: single-GPU runs of the metric's own workload only
         # ---- per-stage event times of the cross-attention sub-path in the timed region ----
         result["stage_ms"] = {k: {"mean": round(avg_ms(v), 4), "max": round(max(a.elapsed_time(b) for a, b in v), 4),
                                   "min": round(min(a.elapsed_time(b) for a, b in v), 4), "launches_per_step": len(v) // args.steps}
                               for k, v in events.items()}
         # ---- the same workload in the other precision modes ----
         for mode in MODES:
-            if mode == args.precision:
+            if mode == prec:
                 continue
             pipe.set_precision(mode)
             n_it = max(2, args.steps // 2)
             ms = event_ms(lambda: pipe(pts, off, patches), iters=n_it, warm=2)
             mode_values[mode] = round(tokens_per_step / ms * 1e3, 1)
-        pipe.set_precision(args.precision)
+        pipe.set_precision(prec)
         result["value_by_mode"] = mode_values
         # ---- Dist-U scenes (SURVEY 8d cfg-2 asks for both distributions): ~1 point per voxel, worst case for the voxelisers ----
         cfg_u = P.PipelineConfig(dist="U")
@@ -356,56 +432,78 @@ def main():
         result["value_dist_u"] = {"value": round(tokens_per_step / ms_u * 1e3, 1), "ms_per_step": round(ms_u, 3),
                                   "note": "same pipeline and mode on Dist-U scenes (seed 1002+i); `value` is Dist-C"}
         del pu, ou, pau
+        # ---- the reference's default depth: VATLiDAR(n_layers = 4); `value` is the BASELINE config's single layer (blocks 1..3 stream every
+        # key through the unsigned tiled kernel: their queries depend on the scene) ----
+        try:
+            cfg4l = P.PipelineConfig(n_layers=4)
+            p4 = P.FusionPipeline(cfg4l, dev, precision=prec)
+            s4 = min(S, 8)
+            b4 = P.synthetic_batch(cfg4l, s4, 1100, dev)
+            ms4 = event_ms(lambda: p4(*b4[:3]), iters=3, warm=2)
+            result["value_n_layers_4"] = {"value": round(s4 * cfg4l.n_queries / ms4 * 1e3, 1), "ms_per_step": round(ms4, 3), "scenes_per_step": s4,
+                                          "note": "VATLiDAR with the reference's default n_layers = 4 (vat_lidar.py:67); `value` uses BASELINE's L = 1"}
+            del p4, b4
+        except Exception as err:                                # never let a secondary figure cost the line
+            result["value_n_layers_4"] = {"error": str(err)[:200]}
         # ---- every cross-attention row of SURVEY 8d, all modes; the first row is the literal headline shape ----
         ca = cross_attention_rows(P, fusion, dev)
         result["cross_attention_rows"] = ca
         hl = ca["32k pts x 196 patches (headline)"]
-        tr, src = profile_traffic(["cross_attn_32768x196 " + args.precision])
-        result["roofline_headline"] = {"bound": "mfma", "kernel": "ca sub-path at (B,Nq,Nkv,d,h) = (1,32768,196,768,12): ca_ln, Q / K|V / out projections, attention, residual",
-                                       "mode": args.precision, "achieved": hl[args.precision]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": hl[args.precision]["frac_of_bf16_peak"], "flops": hl["flops"], "ms": hl[args.precision]["ms"],
-                                       "traffic": tr, "traffic_source": src}
-        # context: the sub-path is five launches over a 32768 x 768 activation -- as built it moves 24 B (bf16) / 36 B (hi + lo modes) per
-        # activation element (fp32 in, bf16 LN out, Q, O, fp32 residual in, fp32 out), i.e. its HBM floor is ABOVE its MFMA floor
-        b_el = 24.0 if args.precision == "bf16" else 36.0
-        hb = b_el * 32768 * 768 + 2.0 * 196 * 768 * 4
-        result["roofline_headline"].update({"hbm_bytes_as_built": hb, "hbm_floor_ms": round(hb / (PEAK_HBM_GBS * 1e9) * 1e3, 4),
-                                            "mfma_floor_ms": round(hl["flops"] / (PEAK_BF16_TFLOPS * 1e12) * 1e3, 4),
-                                            "hbm_frac": round(hb / (hl[args.precision]["ms"] * 1e-3) / (PEAK_HBM_GBS * 1e9), 4)})
         result["cross_attn_32768x196"] = {"flops": hl["flops"], **{m: hl[m] for m in MODES}}
         # ---- HBM-bound side: hard / fused-mean / dynamic voxelisers at cfg-3 ----
         hard, mean, dyn, vscenes = voxel_blocks(dev)
         result["voxelise_cfg3"] = hard
         result["voxelise_mean_cfg3"] = mean
         result["voxelise_dynamic_cfg3"] = dyn
-    else:
-        vscenes = None
 
     # ---- CPU baseline: the oracle restatement on the host cores, bounded sample; parity of every timed mode against it ----
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and wl == "cfg2":
         from oracle import pipeline_oracle as PO
         cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
         sd = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
         sds = (sd(pipe.pillar_vfe), sd(pipe.vat_lidar), sd(pipe.fuse))
-        t1 = time.perf_counter()
-        ref = PO.run(cfg, pts_np[:1], patches_np[:1], *sds)
-        cpu_s = time.perf_counter() - t1
-        result["cpu_baseline"] = {"value": round(cfg.n_queries / cpu_s, 2), "unit": "fused tokens/s", "cores": torch.get_num_threads(),
-                                  "kind": "port", "sample": f"1 scene of the same workload end to end, one run ({cpu_s:.1f} s: a second run would "
-                                  f"double the bounded sample; torch fp32 {torch.get_num_threads()} threads; voxeliser single-threaded C like spconv's CPU generator)"}
+        # thread sweep on a reduced sample (1/16 of the BEV: 128 x 128 cells; same code path), 1 warm-up + 3 runs each; the full-size
+        # sample then runs at the best thread count (256 threads on a 1-scene VATLiDAR oversubscribe the GEMMs)
+        cfg_s = P.PipelineConfig(voxel_pillar=(0.8, 0.8, 8.0))
+        sweep = {}
+        for nt in sorted({t for t in (32, 64, 128, 256) if t <= cores} | {min(cores, 16)}):
+            torch.set_num_threads(nt)
+            PO.run(cfg_s, pts_np[:1], patches_np[:1], *sds, do_3d=False)
+            ts = []
+            for _ in range(3):
+                t1 = time.perf_counter()
+                PO.run(cfg_s, pts_np[:1], patches_np[:1], *sds, do_3d=False)
+                ts.append(time.perf_counter() - t1)
+            sweep[nt] = round(float(np.median(ts)), 3)
+        best_t = min(sweep, key=sweep.get)
+        torch.set_num_threads(best_t)
+        n_par = 3 if not args.no_extras else 1                  # scenes checked for parity (the first is also the timed sample)
+        refs, runs = [], []
+        for i in range(n_par):
+            t1 = time.perf_counter()
+            refs.append(PO.run(cfg, pts_np[i:i + 1], patches_np[i:i + 1], *sds))
+            runs.append(time.perf_counter() - t1)
+        cpu_s = float(np.median(runs[1:])) if len(runs) > 2 else float(min(runs))      # the first run is the warm-up when there are three
+        result["cpu_baseline"] = {"value": round(cfg.n_queries / cpu_s, 2), "unit": "fused tokens/s", "cores": best_t, "host_cores": cores,
+                                  "kind": "port", "thread_sweep_s_on_reduced_sample": sweep,
+                                  "sample": f"{n_par} scene(s) of the same workload end to end, one after the other (run times {[round(r, 1) for r in runs]} s; value = "
+                                  f"median after the first, which warms up); torch fp32 on {best_t} threads = the best of the sweep {sorted(sweep)} taken on a "
+                                  "1/16-size BEV; voxeliser single-threaded C like spconv's CPU generator"}
         if vscenes is not None:
             result["cpu_baseline"]["voxelise_cfg3_cpu"] = cpu_voxel_baseline(vscenes)
         parity = {}
-        for mode in (MODES if not args.no_extras else (args.precision,)):
+        for mode in (MODES if not args.no_extras else (prec,)):
             pipe.set_precision(mode)
             out = pipe(pts, off, patches)
-            err = (out["fused"][0].cpu() - ref["fused"][0]).abs().max().item()
-            parity[mode] = {"fused_max_abs_err": round(err, 6), "meets_1e-3": bool(err <= TOL), "value": mode_values.get(mode)}
-        pipe.set_precision(args.precision)
-        result["parity_vs_cpu"] = {"dtype": args.precision, "fused_max_abs_err": parity[args.precision]["fused_max_abs_err"],
-                                   "fused_ref_absmax": round(ref["fused"].abs().max().item(), 4), "tolerance": TOL,
-                                   "value_meets_tolerance": parity[args.precision]["meets_1e-3"], "modes": parity}
+            errs = [(out["fused"][i].cpu() - refs[i]["fused"][0]).abs().max().item() for i in range(n_par)]
+            parity[mode] = {"fused_max_abs_err": round(max(errs), 6), "per_scene": [round(e, 6) for e in errs], "meets_1e-3": bool(max(errs) <= TOL),
+                            "value": mode_values.get(mode)}
+        pipe.set_precision(prec)
+        result["parity_vs_cpu"] = {"dtype": prec, "fused_max_abs_err": parity[prec]["fused_max_abs_err"], "scenes": n_par,
+                                   "fused_ref_absmax": round(max(r["fused"].abs().max().item() for r in refs), 4), "tolerance": TOL,
+                                   "value_meets_tolerance": parity[prec]["meets_1e-3"], "modes": parity,
+                                   "note": "worst of the checked scenes (seeds 1100 + i); the cross-attention kernel of `roofline` is checked against the same "
+                                           "oracle in tests/test_gpu_ca_fused.py (fp16 operands: 4.4e-4 at the headline shape)"}
     gc.enable()
     print(json.dumps(result), flush=True)
     D.finalize()
