@@ -278,12 +278,7 @@ def main():
         else:
             fused = fuse(lt, im)
             loss, logits = head(im, fused)
-        # one fused buffer [loss * S | S | sum over scenes of the 32 x V answer logits], one all-reduce
-        red[0:1] = loss * float(S)
-        red[1:2].fill_(float(S))
-        red[2:] = logits.sum(0).reshape(-1)
-        if D.is_dist():
-            torch.distributed.all_reduce(red, op=torch.distributed.ReduceOp.SUM)
+        D.reduce_head_step(loss, logits, red)     # one fused buffer [loss * S | S | answer-logit sums], one all-reduce
         return fused
 
     ops.EVENTS = {}                 # event recording is on during warm-up too (first-use costs stay out of the timed region)

@@ -91,6 +91,20 @@ def reduce_step(per_scene: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
     return buf
 
 
+def reduce_head_step(loss: torch.Tensor, answer_logits: torch.Tensor, buf: torch.Tensor) -> torch.Tensor:
+    """Head attached (BASELINE configs[3] / [4]): buf = [loss * S | S | sum over this rank's S scenes of the answer logits
+    [n_answer, V]] and ONE all-reduce(SUM); afterwards buf[0] / buf[1] is the global mean loss and buf[2:] / buf[1] the mean answer logits
+    (all-reducing logits of different scenes only makes sense as a sum / mean).  loss: 0-d (the mean over the rank's scenes);
+    answer_logits [S, n_answer, V]; buf [2 + n_answer * V] fp32.  Stream-ordered; returns buf."""
+    S = answer_logits.shape[0]
+    buf[0:1] = loss.reshape(1) * float(S)
+    buf[1:2].fill_(float(S))
+    buf[2:] = answer_logits.sum(0).reshape(-1)
+    if is_dist():
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf
+
+
 def all_reduce_mean(payload: torch.Tensor, count: float) -> torch.Tensor:
     """commu_utils.all_reduce(data, 'sum', average=True) with the count folded into the same buffer."""
     buf = torch.cat((payload.reshape(-1).float(), torch.tensor([count], dtype=torch.float32, device=payload.device)))
