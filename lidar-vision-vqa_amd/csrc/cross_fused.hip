@@ -440,119 +440,173 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
     f32x16 cpart;
 #pragma unroll
     for (int r = 0; r < 16; ++r) cpart[r] = (32 * (KC - 1) + (r & 3) + 8 * (r >> 2) + 4 * h2) < a.nkv ? 0.f : -INFINITY;
-    // ================================ B: attention, one head per iteration ================================
-    static_for<0, NH>([&](auto hi) {
+    // ================================ B: attention, software-pipelined over the heads ================================
+    // A head's softmax is ~440 vector instructions against 56 MFMAs, and a lone wave per SIMD overlaps the two only inside its own
+    // instruction stream.  So the K|V stream is ordered K0 K1 V0 K2 V1 ... K11 V10 V11 (half-blocks of 8 batches: 7 key blocks + 1 pad)
+    // and head h's softmax rides in the MFMA shadows of its neighbours' products:
+    //   under  O(h-1) = V(h-1)^T P(h-1)   the row maximum of S(h)          (4 scores per MFMA)
+    //   under  S(h+1) = K(h+1) Q(h+1)^T   exp2 / row sum / pack of P(h)    (4 scores per MFMA)
+    // Scores and packed P are double-buffered by head parity.  Each batch issues: MFMA, vector slice, the stream's requests (mid), x 4.
+    constexpr int B0 = 0;                                       // phase B is one 192-batch body for the step bookkeeping
+    using CfgB = StepCfg<24 * 8, false, false>;
+    f32x16 sacc[2][KC];
+    uint32_t pw[2][KC][8];                                      // packed P of a head: [key block][word]: words 0..3 = k-step 0, 4..7 = k-step 1
+    f32x16 o0, o1;
+    float mrow[2] = {0.f, 0.f}, lsum[2] = {0.f, 0.f}, linv[2] = {0.f, 0.f};
+    auto pfrag = [&](int par, int kb, int t) __attribute__((always_inline)) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 u = {pw[par][kb][4 * t], pw[par][kb][4 * t + 1], pw[par][kb][4 * t + 2], pw[par][kb][4 * t + 3]};
+        return __builtin_bit_cast(h16x8, u);
+    };
+    // vector slices (i = 0 .. 4 KC - 1): four scores of key block i / 4, registers 4 (i % 4) .. + 3
+    auto sm_max = [&](auto hi, auto ii) __attribute__((always_inline)) {
+        constexpr int h = decltype(hi)::value, i = decltype(ii)::value, par = h & 1, kb = i / 4, q4 = (i % 4) * 4;
+        if constexpr (DBG & 16) return;
+        const f32x16 &sv = sacc[par][kb];
+        float m = i == 0 ? -INFINITY : mrow[par];
+        m = __builtin_fmaxf(__builtin_fmaxf(m, sv[q4]), sv[q4 + 1]);
+        m = __builtin_fmaxf(__builtin_fmaxf(m, sv[q4 + 2]), sv[q4 + 3]);
+        if constexpr (i == 4 * KC - 1) m = swap_max(m);
+        mrow[par] = m;
+    };
+    auto sm_exp = [&](auto hi, auto ii) __attribute__((always_inline)) {
+        constexpr int h = decltype(hi)::value, i = decltype(ii)::value, par = h & 1, kb = i / 4, q = i % 4;
+        if constexpr (DBG & 16) return;
+        const f32x16 &sv = sacc[par][kb];
+        const float m = mrow[par];
+        const float e0 = __builtin_amdgcn_exp2f(sv[4 * q] - m), e1 = __builtin_amdgcn_exp2f(sv[4 * q + 1] - m);
+        const float e2 = __builtin_amdgcn_exp2f(sv[4 * q + 2] - m), e3 = __builtin_amdgcn_exp2f(sv[4 * q + 3] - m);
+        const float part = (e0 + e1) + (e2 + e3);
+        lsum[par] = i == 0 ? part : lsum[par] + part;
+        pw[par][kb][2 * q] = pack2<F16>(e0, e1);
+        pw[par][kb][2 * q + 1] = pack2<F16>(e2, e3);
+        if constexpr (i == 4 * KC - 1) linv[par] = 1.0f / swap_sum(lsum[par]);
+    };
+    auto normalize = [&](auto hi) __attribute__((always_inline)) {      // O(h) / l -> B fragments of out^T = W_o O^T, into the slots of head h's Q
         constexpr int h = decltype(hi)::value;
-        f32x16 sacc[KC];
-        h16x8 pf[KC][2];
-        h16x8 qh[4];                                            // this head's Q^T fragments
-        f32x16 o0, o1;
-        float linv = 0.f;
-        if (h < QL) {                                           // parked Q: back from LDS (no vector code between the reads and their wait)
-            const uint32_t ph = rs_addr + h * (4 * FRAG);
-            lds_read<0>(qh[0], ph);
-            lds_read<FRAG>(qh[1], ph);
-            lds_read<2 * FRAG>(qh[2], ph);
-            lds_read<3 * FRAG>(qh[3], ph);
-            lds_wait0(qh);                                      // (also retires the first batch's reads, requested just before: harmless)
-        } else {
-            static_for<QL, NH>([&](auto hc) {
-                constexpr int HC = decltype(hc)::value;
-                if (h == HC) {
+        if constexpr (DBG & 16) return;
+        h16x8 fr[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) qh[i] = qf[4 * HC + i];
+        for (int blk = 0; blk < 2; ++blk) {
+            const f32x16 &o = blk ? o1 : o0;
+#pragma unroll
+            for (int sx = 0; sx < 2; ++sx) {
+                float e[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = o[8 * sx + j] * linv[h & 1];
+                fr[2 * blk + sx] = pack8<F16>(e);
+                pin(fr[2 * blk + sx]);
+            }
+        }
+        if constexpr (h < QL) {
+            lds_write<(4 * h + 0) * FRAG>(rs_addr, fr[0]);
+            lds_write<(4 * h + 1) * FRAG>(rs_addr, fr[1]);
+            lds_write<(4 * h + 2) * FRAG>(rs_addr, fr[2]);
+            lds_write<(4 * h + 3) * FRAG>(rs_addr, fr[3]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                qf[4 * h + i] = fr[i];
+                pin(qf[4 * h + i]);
+            }
+        }
+    };
+    // one half-block of the stream = 8 batches; `hb` numbers the half-blocks of phase B (0 .. 23)
+    auto run_batch = [&](auto lbi, auto &&body) __attribute__((always_inline)) {
+        constexpr int LB = decltype(lbi)::value;
+        if constexpr (LB % 2 == 0) step_impl(std::integral_constant<int, B0 + LB>{}, CfgB{}, false, false, 0, FA, FB, body);
+        else step_impl(std::integral_constant<int, B0 + LB>{}, CfgB{}, false, false, 0, FB, FA, body);
+    };
+    h16x8 qh[4];                                                // Q^T fragments of the head whose scores are being computed
+    auto load_q = [&](auto hi) __attribute__((always_inline)) {
+        constexpr int h = decltype(hi)::value;
+        if constexpr (h < QL) {                                 // parked Q: back from LDS (no vector code between the reads and their wait)
+            lds_read<(4 * h + 0) * FRAG>(qh[0], rs_addr);
+            lds_read<(4 * h + 1) * FRAG>(qh[1], rs_addr);
+            lds_read<(4 * h + 2) * FRAG>(qh[2], rs_addr);
+            lds_read<(4 * h + 3) * FRAG>(qh[3], rs_addr);
+            lds_wait0(qh);                                      // (also retires the next batch's reads, requested just before: harmless)
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qh[i] = qf[4 * h + i];
+        }
+    };
+    // S(hs) = K(hs) Q(hs)^T over half-block hb, with softmax slices of head hv (exp pass) in the shadows when hv >= 0
+    auto s_block = [&](auto hbi, auto hsi, auto hvi) __attribute__((always_inline)) {
+        constexpr int hb = decltype(hbi)::value, hs = decltype(hsi)::value, hv = decltype(hvi)::value, par = hs & 1;
+        load_q(hsi);
+        static_for<0, 8>([&](auto li) {
+            constexpr int lb = decltype(li)::value;
+            run_batch(std::integral_constant<int, 8 * hb + lb>{}, [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
+                auto vs = [&](auto si) __attribute__((always_inline)) {
+                    constexpr int i = 4 * lb + decltype(si)::value;
+                    if constexpr (hv >= 0 && i < 4 * KC) sm_exp(std::integral_constant<int, hv < 0 ? 0 : hv>{}, std::integral_constant<int, i < 4 * KC ? i : 0>{});
+                };
+                if constexpr (lb < KC) {                        // S^T block lb = K rows 32 lb .. + 31 against Q^T (4 k-steps over dh)
+                    sacc[par][lb] = mfma_d(f[0], qh[0], lb == KC - 1 ? cpart : zero);
+                    vs(M0);
+                    mid(M0);
+                    sacc[par][lb] = mfma_d(f[1], qh[1], sacc[par][lb]);
+                    vs(M1);
+                    mid(M1);
+                    sacc[par][lb] = mfma_d(f[2], qh[2], sacc[par][lb]);
+                    vs(M2);
+                    mid(M2);
+                    sacc[par][lb] = mfma_d(f[3], qh[3], sacc[par][lb]);
+                    vs(std::integral_constant<int, 3>{});
+                } else {                                        // padding of the half-block to whole groups
+                    mid(M0);
+                    mid(M1);
+                    mid(M2);
                 }
             });
-        }
-        static_for<0, 4 * CG>([&](auto li) {
-            constexpr int lb = decltype(li)::value;
-            using Cfg = StepCfg<4 * CG, false, lb == KC - 1 || lb == 2 * KC - 1>;
-            auto body = [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
-                if constexpr (lb < KC) {                        // S^T block lb = K rows 32 lb .. + 31 against Q^T (4 k-steps over dh)
-                    sacc[lb] = mfma_d(f[0], qh[0], lb == KC - 1 ? cpart : zero);
-                    mid(M0);
-                    sacc[lb] = mfma_d(f[1], qh[1], sacc[lb]);
-                    mid(M1);
-                    sacc[lb] = mfma_d(f[2], qh[2], sacc[lb]);
-                    mid(M2);
-                    sacc[lb] = mfma_d(f[3], qh[3], sacc[lb]);
-                    if constexpr (lb == KC - 1 && !(DBG & 16)) {               // softmax over the row's keys: 16 KC scores in this lane + as many in lane ^ 32
-                        float m = -INFINITY;
-#pragma unroll
-                        for (int kb = 0; kb < KC; ++kb)
-#pragma unroll
-                            for (int r = 0; r < 16; r += 2) m = __builtin_fmaxf(__builtin_fmaxf(m, sacc[kb][r]), sacc[kb][r + 1]);
-                        m = swap_max(m);
-                        float l0 = 0.f, l1 = 0.f;
-#pragma unroll
-                        for (int kb = 0; kb < KC; ++kb) {
-#pragma unroll
-                            for (int t = 0; t < 2; ++t) {
-                                float e[8];
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(sacc[kb][8 * t + j] - m);
-                                l0 += (e[0] + e[1]) + (e[2] + e[3]);
-                                l1 += (e[4] + e[5]) + (e[6] + e[7]);
-                                pf[kb][t] = pack8<F16>(e);
-                                pin(pf[kb][t]);
-                            }
-                        }
-                        linv = 1.0f / swap_sum(l0 + l1);
-                    }
-                } else if constexpr (lb < 2 * KC) {             // O^T += V^T P^T over key block kb (2 k-steps x 2 dh-blocks)
-                    constexpr int kb = lb - KC;
-                    if constexpr (kb == 0) o0 = mfma_d(f[0], pf[kb][0], zero);
-                    else o0 = mfma_d(f[0], pf[kb][0], o0);
-                    mid(M0);
-                    if constexpr (kb == 0) o1 = mfma_d(f[1], pf[kb][0], zero);
-                    else o1 = mfma_d(f[1], pf[kb][0], o1);
-                    mid(M1);
-                    o0 = mfma_d(f[2], pf[kb][1], o0);
-                    mid(M2);
-                    o1 = mfma_d(f[3], pf[kb][1], o1);
-                    if constexpr (kb == KC - 1 && !(DBG & 16)) {               // normalise -> B fragments of out^T = W_o O^T, into the slots of this head's Q
-                        h16x8 fr[4];
-#pragma unroll
-                        for (int blk = 0; blk < 2; ++blk) {
-                            const f32x16 &o = blk ? o1 : o0;
-#pragma unroll
-                            for (int sx = 0; sx < 2; ++sx) {
-                                float e[8];
-#pragma unroll
-                                for (int j = 0; j < 8; ++j) e[j] = o[8 * sx + j] * linv;
-                                fr[2 * blk + sx] = pack8<F16>(e);
-                                pin(fr[2 * blk + sx]);
-                            }
-                        }
-                        if (h < QL) {
-                            const uint32_t ph = rs_addr + h * (4 * FRAG);
-                            lds_write<0>(ph, fr[0]);
-                            lds_write<FRAG>(ph, fr[1]);
-                            lds_write<2 * FRAG>(ph, fr[2]);
-                            lds_write<3 * FRAG>(ph, fr[3]);
-                        } else {
-                            static_for<QL, NH>([&](auto hc) {
-                                constexpr int HC = decltype(hc)::value;
-                                if (h == HC) {
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) {
-                                        qf[4 * HC + i] = fr[i];
-                                        pin(qf[4 * HC + i]);
-                                    }
-                                }
-                            });
-                        }
-                    }
-                } else {                                        // lb >= 2 KC: padding of the (batch, head) segment to whole groups
-                    mid(M0);
-                    mid(M1);
-                    mid(M2);
-                }
-            };
-            if constexpr (lb % 2 == 0) step_impl(std::integral_constant<int, lb>{}, Cfg{}, false, false, 0, FA, FB, body);
-            else step_impl(std::integral_constant<int, lb>{}, Cfg{}, false, false, 0, FB, FA, body);
         });
+    };
+    // O(hp) = V(hp)^T P(hp) over half-block hb, with the row maximum of head hv in the shadows when hv >= 0; normalises O(hp) at the end
+    auto pv_block = [&](auto hbi, auto hpi, auto hvi) __attribute__((always_inline)) {
+        constexpr int hb = decltype(hbi)::value, hp = decltype(hpi)::value, hv = decltype(hvi)::value, par = hp & 1;
+        static_for<0, 8>([&](auto li) {
+            constexpr int lb = decltype(li)::value;
+            run_batch(std::integral_constant<int, 8 * hb + lb>{}, [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
+                auto vs = [&](auto si) __attribute__((always_inline)) {
+                    constexpr int i = 4 * lb + decltype(si)::value;
+                    if constexpr (hv >= 0 && i < 4 * KC) sm_max(std::integral_constant<int, hv < 0 ? 0 : hv>{}, std::integral_constant<int, i < 4 * KC ? i : 0>{});
+                };
+                if constexpr (lb < KC) {                        // O^T += V^T P^T over key block lb (2 k-steps x 2 dh-blocks)
+                    if constexpr (lb == 0) o0 = mfma_d(f[0], pfrag(par, lb, 0), zero);
+                    else o0 = mfma_d(f[0], pfrag(par, lb, 0), o0);
+                    vs(M0);
+                    mid(M0);
+                    if constexpr (lb == 0) o1 = mfma_d(f[1], pfrag(par, lb, 0), zero);
+                    else o1 = mfma_d(f[1], pfrag(par, lb, 0), o1);
+                    vs(M1);
+                    mid(M1);
+                    o0 = mfma_d(f[2], pfrag(par, lb, 1), o0);
+                    vs(M2);
+                    mid(M2);
+                    o1 = mfma_d(f[3], pfrag(par, lb, 1), o1);
+                    vs(std::integral_constant<int, 3>{});
+                } else {
+                    mid(M0);
+                    mid(M1);
+                    mid(M2);
+                    normalize(hpi);
+                }
+            });
+        });
+    };
+    constexpr std::integral_constant<int, -1> NONE{};
+    s_block(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, NONE);              // K0
+    static_for<0, 4 * KC>([&](auto i) { sm_max(std::integral_constant<int, 0>{}, i); });            // row maximum of head 0: no product to hide under
+    s_block(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});     // K1 with exp(S0)
+    static_for<1, NH>([&](auto hi) {
+        constexpr int h = decltype(hi)::value;
+        // V(h-1) with max(S(h)); then K(h+1) with exp(S(h)) -- or, for the last head, the exp pass alone
+        pv_block(std::integral_constant<int, 2 * h>{}, std::integral_constant<int, h - 1>{}, hi);
+        if constexpr (h + 1 < NH) s_block(std::integral_constant<int, 2 * h + 1>{}, std::integral_constant<int, h + 1>{}, hi);
+        else static_for<0, 4 * KC>([&](auto i) { sm_exp(hi, i); });
     });
+    pv_block(std::integral_constant<int, 23>{}, std::integral_constant<int, NH - 1>{}, NONE);       // V11
 
     stamp(4);
     // ================================ C: out^T = W_o O^T in chunks of 128 columns, + b_o + residual ================================
@@ -685,7 +739,9 @@ template <bool F16> __global__ void __launch_bounds__(KVW * 64) k_ca_kvproj(KvAr
         for (int w = 0; w < KVW; ++w) t += red[((size_t)(w * 4 + wid) * 16 + r) * 64 + lane];
         s[r] = t;
     }
-    char *seg = a.out + ((int64_t)b * NH + h) * a.cf * FRAG;
+    // stream order of the fused kernel's phase B: K0 K1 V0 K2 V1 ... K11 V10 V11, half-blocks of 32 fragments
+    const int kpos = h < 2 ? h : 2 * h - 1, vpos = h < NH - 1 ? 2 + 2 * h : 2 * NH - 1;
+    char *segk = a.out + ((int64_t)b * 2 * NH + kpos) * 32 * FRAG, *segv = a.out + ((int64_t)b * 2 * NH + vpos) * 32 * FRAG;
     if (wid < 2) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] += a.bk[64 * h + 32 * wid + (r & 3) + 8 * (r >> 2) + 4 * h2];       // row of the K^T block = dh
@@ -694,7 +750,7 @@ template <bool F16> __global__ void __launch_bounds__(KVW * 64) k_ca_kvproj(KvAr
             float e[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) e[j] = s[8 * sp + j];
-            *reinterpret_cast<h16x8 *>(seg + (int64_t)(kb * 4 + 2 * wid + sp) * FRAG + lane * 16) = pack8<F16, true>(e);
+            *reinterpret_cast<h16x8 *>(segk + (int64_t)(kb * 4 + 2 * wid + sp) * FRAG + lane * 16) = pack8<F16, true>(e);
         }
     } else {
         const int blk = wid - 2;
@@ -704,7 +760,7 @@ template <bool F16> __global__ void __launch_bounds__(KVW * 64) k_ca_kvproj(KvAr
             float e[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) e[j] = s[8 * t + j] + bv;
-            *reinterpret_cast<h16x8 *>(seg + (int64_t)(4 * a.kc + kb * 4 + 2 * t + blk) * FRAG + lane * 16) = pack8<F16, true>(e);
+            *reinterpret_cast<h16x8 *>(segv + (int64_t)(kb * 4 + 2 * t + blk) * FRAG + lane * 16) = pack8<F16, true>(e);
         }
     }
 }
