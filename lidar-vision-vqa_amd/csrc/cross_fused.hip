@@ -366,71 +366,87 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
 
     stamp(2);
     if (a.stamps && lane == 0) a.stamps[((int64_t)blockIdx.x * NW + wid) * 8 + 6] = __builtin_amdgcn_s_memtime();
-    // ================================ A: Q^T = W_q' LN(x)^T, two heads per iteration ================================
-    static_for<0, NH / 2>([&](auto hpi) {
-        constexpr int hp = decltype(hpi)::value;
-        static_for<0, 2>([&](auto hhi) {
-            constexpr int hh = decltype(hhi)::value;
-            constexpr int h = 2 * hp + hh;
-            f32x16 acc0, acc1;
-            static_for<0, 24>([&](auto li) {
-                constexpr int lb = decltype(li)::value, ks = 2 * lb, LB = 24 * hh + lb;
-                using Cfg = StepCfg<48, false, lb == 23>;
-                auto body = [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
-                    if constexpr (lb == 0) acc0 = mfma_d(f[0], xd[ks], zero);
-                    else acc0 = mfma_d(f[0], xd[ks], acc0);
-                    mid(M0);
-                    if constexpr (lb == 0) acc1 = mfma_d(f[1], xd[ks], zero);
-                    else acc1 = mfma_d(f[1], xd[ks], acc1);
-                    mid(M1);
-                    acc0 = mfma_d(f[2], xd[ks + 1], acc0);
-                    mid(M2);
-                    acc1 = mfma_d(f[3], xd[ks + 1], acc1);
-                    if constexpr (lb == 23 && !(DBG & 16)) {
-                        // Q^T (scaled by log2(e) / sqrt(dh)) = acc * q_a - rowsum(W') * q_b + bias' -> B fragments of S^T = K Q^T;
-                        // row (= dh) of register r of block blk: 32 blk + (r & 3) + 8 (r >> 2) + 4 h2
-                        const uint32_t th = tb_addr + h * (64 * 4);
-                        h16x8 fr[4];
-                        static_for<0, 4>([&](auto ui) {
-                            constexpr int blk = decltype(ui)::value >> 1, sx = decltype(ui)::value & 1;
-                            f32x4 t[4];                           // t[0..1] bias', t[2..3] row sums: rows 64 h + 32 blk + 16 sx + 8 g + 4 h2 .. + 3
-                            lds_read<(32 * blk + 16 * sx) * 4>(t[0], th);
-                            lds_read<(32 * blk + 16 * sx + 8) * 4>(t[1], th);
-                            lds_read<(D + 32 * blk + 16 * sx) * 4>(t[2], th);
-                            lds_read<(D + 32 * blk + 16 * sx + 8) * 4>(t[3], th);
-                            lds_wait0(t);
-                            const f32x16 &acc = blk ? acc1 : acc0;
-                            float e[8];
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) e[j] = __builtin_fmaf(acc[8 * sx + j], q_a, __builtin_fmaf(-t[2 + (j >> 2)][j & 3], q_b, t[j >> 2][j & 3]));
-                            fr[2 * blk + sx] = pack8<F16, true>(e);
-                            pin(fr[2 * blk + sx]);
-                            __builtin_amdgcn_sched_barrier(0);    // keep the four units apart (their table reads would otherwise be hoisted together)
-                        });
-                        if (h < QL) {                             // parked in LDS
-                            const uint32_t ph = rs_addr + h * (4 * FRAG);
-                            lds_write<0>(ph, fr[0]);
-                            lds_write<FRAG>(ph, fr[1]);
-                            lds_write<2 * FRAG>(ph, fr[2]);
-                            lds_write<3 * FRAG>(ph, fr[3]);
-                        } else {
-                            static_for<QL, NH>([&](auto hc) {
-                                constexpr int HC = decltype(hc)::value;
-                                if (h == HC) {
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i) {
-                                        qf[4 * HC + i] = fr[i];
-                                        pin(qf[4 * HC + i]);
-                                    }
-                                }
-                            });
-                        }
+    // ================================ A: Q^T = W_q' LN(x)^T, head by head ================================
+    // The epilogue of head h (acc * q_a - rowsum(W') * q_b + bias' -> 16-bit B fragments of S^T = K Q^T) rides in the MFMA shadows of
+    // head h + 1's first batches: accumulators are double-buffered by head parity.  Four units (dh-block blk, half sx); unit u reads
+    // its four table vectors at the end of batch 2 u and computes in batch 2 u + 1 (the batch-start wait has retired the reads).
+    f32x16 qacc[2][2];                                           // [head parity][dh-block]
+    f32x4 tq4[4];                                                // table vectors of the unit in flight: bias' (2), row sums (2)
+    h16x8 qfr[4];
+    auto q_unit_read = [&](auto hi, auto ui) __attribute__((always_inline)) {
+        constexpr int h = decltype(hi)::value, blk = decltype(ui)::value >> 1, sx = decltype(ui)::value & 1;
+        if constexpr (DBG & 16) return;
+        lds_read<(64 * h + 32 * blk + 16 * sx) * 4>(tq4[0], tb_addr);
+        lds_read<(64 * h + 32 * blk + 16 * sx + 8) * 4>(tq4[1], tb_addr);
+        lds_read<(D + 64 * h + 32 * blk + 16 * sx) * 4>(tq4[2], tb_addr);
+        lds_read<(D + 64 * h + 32 * blk + 16 * sx + 8) * 4>(tq4[3], tb_addr);
+    };
+    // quarter qq of unit u: two of its eight values per call... (row = dh of register r of block blk: 32 blk + (r & 3) + 8 (r >> 2) + 4 h2)
+    uint32_t qw[4];
+    auto q_unit_quarter = [&](auto hi, auto ui, auto qi) __attribute__((always_inline)) {
+        constexpr int h = decltype(hi)::value, u = decltype(ui)::value, blk = u >> 1, sx = u & 1, qq = decltype(qi)::value;
+        if constexpr (DBG & 16) return;
+        if constexpr (qq == 0) asm volatile("" : "+v"(tq4[0]), "+v"(tq4[1]), "+v"(tq4[2]), "+v"(tq4[3]));      // behind the batch-start wait (asm order)
+        const f32x16 &acc = qacc[h & 1][blk];
+        float e0, e1;
+        {
+            constexpr int j = 2 * qq;
+            e0 = __builtin_fmaf(acc[8 * sx + j], q_a, __builtin_fmaf(-tq4[2 + (j >> 2)][j & 3], q_b, tq4[j >> 2][j & 3]));
+            e1 = __builtin_fmaf(acc[8 * sx + j + 1], q_a, __builtin_fmaf(-tq4[2 + ((j + 1) >> 2)][(j + 1) & 3], q_b, tq4[(j + 1) >> 2][(j + 1) & 3]));
+        }
+        if (F16) e0 = clamp16(e0), e1 = clamp16(e1);
+        qw[qq] = pack2<F16>(e0, e1);
+        if constexpr (qq == 3) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 w4 = {qw[0], qw[1], qw[2], qw[3]};
+            h16x8 fr = __builtin_bit_cast(h16x8, w4);
+            pin(fr);
+            if constexpr (h < QL) lds_write<(4 * h + u) * FRAG>(rs_addr, fr);
+            else {
+                qf[4 * h + u] = fr;
+                pin(qf[4 * h + u]);
+            }
+        }
+    };
+    static_for<0, NH>([&](auto hi) {
+        constexpr int h = decltype(hi)::value, par = h & 1;
+        static_for<0, 24>([&](auto li) {
+            constexpr int lb = decltype(li)::value, ks = 2 * lb, LB = 24 * h + lb;
+            using Cfg = StepCfg<NH * 24, false, false>;
+            auto body = [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
+                // epilogue slices of the previous head: batches 0, 2, 4, 6 end with a unit's table reads, batches 1, 3, 5, 7 compute it
+                auto vs = [&](auto si) __attribute__((always_inline)) {
+                    constexpr int sl = decltype(si)::value;
+                    if constexpr (h > 0 && lb < 8) {
+                        constexpr int u = lb / 2;
+                        if constexpr (lb % 2 == 1) q_unit_quarter(std::integral_constant<int, (h > 0 ? h - 1 : 0)>{}, std::integral_constant<int, u>{}, si);
+                        else if constexpr (sl == 3) q_unit_read(std::integral_constant<int, (h > 0 ? h - 1 : 0)>{}, std::integral_constant<int, u>{});
                     }
                 };
-                if constexpr (LB % 2 == 0) step_impl(std::integral_constant<int, LB>{}, Cfg{}, hp == 0, false, 0, FA, FB, body);
-                else step_impl(std::integral_constant<int, LB>{}, Cfg{}, hp == 0, false, 0, FB, FA, body);
-            });
+                if constexpr (lb == 0) qacc[par][0] = mfma_d(f[0], xd[ks], zero);
+                else qacc[par][0] = mfma_d(f[0], xd[ks], qacc[par][0]);
+                vs(M0);
+                mid(M0);
+                if constexpr (lb == 0) qacc[par][1] = mfma_d(f[1], xd[ks], zero);
+                else qacc[par][1] = mfma_d(f[1], xd[ks], qacc[par][1]);
+                vs(M1);
+                mid(M1);
+                qacc[par][0] = mfma_d(f[2], xd[ks + 1], qacc[par][0]);
+                vs(M2);
+                mid(M2);
+                qacc[par][1] = mfma_d(f[3], xd[ks + 1], qacc[par][1]);
+                vs(std::integral_constant<int, 3>{});
+            };
+            if constexpr (LB % 2 == 0) step_impl(std::integral_constant<int, LB>{}, Cfg{}, h == 0, false, 0, FA, FB, body);
+            else step_impl(std::integral_constant<int, LB>{}, Cfg{}, h == 0, false, 0, FB, FA, body);
         });
+    });
+    // the last head's epilogue has no projection left to hide under (the next batch's fragment reads are in flight: requested by the last step)
+    static_for<0, 4>([&](auto ui) {
+        q_unit_read(std::integral_constant<int, NH - 1>{}, ui);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tq4[0]), "+v"(tq4[1]), "+v"(tq4[2]), "+v"(tq4[3])::"memory");
+        static_for<0, 4>([&](auto qi) { q_unit_quarter(std::integral_constant<int, NH - 1>{}, ui, qi); });
+        __builtin_amdgcn_sched_barrier(0);
     });
 
     stamp(3);
