@@ -134,6 +134,39 @@ def voxel_blocks(dev):
     return hard, mean, dyn, scenes
 
 
+def voxel_scaling(dev):
+    """The three voxelisers at sizes where bandwidth rather than the ~5 us floor of each dependent launch decides:
+    cfg-3 (8 x 65 536), 32 x 65 536 and 8 x 120 000 points; whole call, HIP events, algorithmic bytes of SURVEY 8d."""
+    from lidar_vision_vqa_amd import lidar as LD, synth as SY
+    rng = list(SY.PC_RANGE_NUSC)
+    grid = LD.grid_size_from(rng, SY.VOXEL_01)
+    out = {}
+    for label, ns, npts in (("8x65536", 8, 65536), ("32x65536", 32, 65536), ("8x120000", 8, 120000)):
+        scenes = [SY.scene_points("C", npts, 1010 + i) for i in range(ns)]
+        lens = [len(x) for x in scenes]
+        pts = torch.from_numpy(np.concatenate(scenes)).to(dev)
+        off = torch.tensor(np.concatenate(([0], np.cumsum(lens))), dtype=torch.int32, device=dev)
+        gen = LD.VoxelGeneratorWrapper(SY.VOXEL_01, rng, 4, 10, 160000)
+        m_vox = int(gen.generate_batch_device(pts, off, ns)[3][-1])
+        n = float(pts.shape[0])
+        us_h = event_ms(lambda: gen.generate_batch_device(pts, off, ns), iters=20) * 1e3
+        us_m = event_ms(lambda: gen.generate_mean_device(pts, off, ns), iters=20) * 1e3
+        entry = {"points": int(n), "voxels": m_vox}
+        for name, us, nb in (("hard", us_h, 16.0 * n + m_vox * (4.0 * 10 * 4 + 16)), ("fused_mean", us_m, 16.0 * n + m_vox * (4.0 * 4 + 16))):
+            entry[name] = {"us": round(us, 1), "GBps": round(nb / us / 1e3, 1), "frac": round(nb / us / 1e3 / PEAK_HBM_GBS, 4)}
+        if ns * grid[0] * grid[1] * grid[2] < 2 ** 31:             # the dynamic voxeliser's int32 key space (SURVEY a7 quirk: scene index x cells)
+            bidx = torch.repeat_interleave(torch.arange(ns, device=dev, dtype=torch.float32), torch.tensor(lens, device=dev))
+            bp = torch.cat((bidx[:, None], pts), 1).contiguous()
+            m_dyn = int(LD._dynamic_voxelize(bp, ns, rng, SY.VOXEL_01, grid, 3)["counts"][0])
+            us_d = event_ms(lambda: LD._dynamic_voxelize(bp, ns, rng, SY.VOXEL_01, grid, 3), iters=20) * 1e3
+            nb = 20.0 * n + 4.0 * n + m_dyn * 24.0
+            entry["dynamic"] = {"us": round(us_d, 1), "GBps": round(nb / us_d / 1e3, 1), "frac": round(nb / us_d / 1e3 / PEAK_HBM_GBS, 4), "voxels": m_dyn}
+            del bp, bidx
+        out[label] = entry
+        del pts, off, gen
+    return out
+
+
 def _vox_worker(args):
     """One scene through the CPU voxeliser restatement (process pool worker: the scene-parallel CPU variant of SURVEY 8d)."""
     pts, vs, rng, T, mv = args
@@ -450,6 +483,10 @@ def main():
         result["voxelise_cfg3"] = hard
         result["voxelise_mean_cfg3"] = mean
         result["voxelise_dynamic_cfg3"] = dyn
+        try:
+            result["voxelise_scaling"] = voxel_scaling(dev)
+        except Exception as err:
+            result["voxelise_scaling"] = {"error": str(err)[:200]}
 
     # ---- CPU baseline: the oracle restatement on the host cores, bounded sample; parity of every timed mode against it ----
     if world == 1 and not args.no_cpu_baseline and wl == "cfg2":

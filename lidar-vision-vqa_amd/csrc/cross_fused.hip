@@ -164,6 +164,22 @@ __device__ __forceinline__ void lds_wait0(f32x4 (&f)[4]) {
 template <int BODY, bool RESID, bool LATE> struct StepCfg {
     static constexpr int body_batches = BODY;
     static constexpr bool resid = RESID, late = LATE;
+    // vector-memory operations OTHER than ring pieces that batch lb of the body issues (phase C: one residual piece in batches 16 .. 31
+    // of a 48-batch chunk, four row stores in batches 9, 11, 13, 15 of every chunk but the first).  vmcnt retires in order, so the counted
+    // wait for a ring piece must allow for every younger operation -- otherwise it waits for the stores' round trip to HBM as well.
+    static constexpr int other_ops(int lb, bool stores) {
+        if (!RESID || lb < 0) return 0;
+        const int l = lb % (D / 16), c = lb / (D / 16);
+        return ((l >= 16 && l < 32) ? 1 : 0) + ((stores && c > 0 && l >= 9 && l < 16 && (l & 1)) ? 4 : 0);
+    }
+    // ... issued after the last ring piece of the group that the wait at the start of batch lb (lb % 4 == 3) is for: that piece went out
+    // in batch lb - 9 (before that batch's fourth vector slot); counted from batch lb - 8 on (a lower bound is safe, an upper bound is not)
+    // (`stores`: a wave without rows of its own issues no stores)
+    static constexpr int younger_other_ops(int lb, bool stores) {
+        int n = 0;
+        for (int b = lb - 8; b < lb; ++b) n += other_ops(b, stores);
+        return n;
+    }
 };
 
 // DBG: timing experiments only (CA_DEBUG_VARIANTS builds; results are wrong): 1 no MFMA, 2 no LDS-DMA after the first ring fill,
@@ -313,7 +329,12 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
                 if constexpr (gl == groups - 3) vm_wait<DPG>();
                 else vm_wait<0>();
             } else {
-                vm_wait<DPG *(NSLOT - 2)>();
+                if constexpr (Cfg::younger_other_ops(LB, true) != Cfg::younger_other_ops(LB, false)) {
+                    if (active) vm_wait<DPG *(NSLOT - 2) + Cfg::younger_other_ops(LB, true)>();
+                    else vm_wait<DPG *(NSLOT - 2) + Cfg::younger_other_ops(LB, false)>();
+                } else {
+                    vm_wait<DPG *(NSLOT - 2) + Cfg::younger_other_ops(LB, false)>();
+                }
             }
             if constexpr (!(DBG & 8)) if (!(last_iter && LASTB)) __builtin_amdgcn_s_barrier();
         }
@@ -337,7 +358,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
                 } else {
                     issue_piece(std::integral_constant<int, u / 4>{}, std::integral_constant<int, u % 4>{});
                 }
-                if constexpr (Cfg::resid && LB >= 4 && LB < 20) issue_resid(chunk, std::integral_constant<int, (LB >= 4 && LB < 20) ? LB - 4 : 0>{});
+                if constexpr (Cfg::resid && LB % NKS >= 16 && LB % NKS < 32) issue_resid(LB / NKS, std::integral_constant<int, (LB % NKS >= 16 && LB % NKS < 32) ? LB % NKS - 16 : 0>{});
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -630,60 +651,90 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
     static_for<0, 4 * QL>([&](auto fi) { lds_read<decltype(fi)::value * FRAG>(qf[decltype(fi)::value], rs_addr); });
 #pragma unroll
     for (int h = 0; h < QL; ++h) lds_wait0_4(qf[4 * h], qf[4 * h + 1], qf[4 * h + 2], qf[4 * h + 3]);
-    for (int c = 0; c < NCHUNK; ++c) {
-            const uint32_t tbo = tb_addr + (2 * D + 128 * c) * 4;
-        f32x16 acc[NBC];
+    // The epilogue of chunk c rides in the MFMA shadows of chunk c + 1's first 16 batches (accumulators double-buffered by chunk parity):
+    //   E1, column block nb (batches 2 nb, 2 nb + 1): out^T (lane = row, registers = columns) + bias is added INTO the residual tile in LDS,
+    //       column-wise (the residual pieces were requested >= 16 batches before the chunk ended: every ring wait since then covered them);
+    //   E2, piece group v (batches 8 + 2 v, 9 + 2 v): the tile leaves row-wise, every store instruction writes two full 512-byte row segments.
+    // A unit's LDS reads are issued at the end of its first batch and consumed in its second (the batch-start wait has retired them).
+    // The residual pieces of chunk c + 1 follow in batches 16 .. 31 (StepCfg::resid), once the tile of chunk c has left.
+    f32x16 oacc[2][NBC];
+    f32x4 te[8];
+    const uint32_t tq = rs_addr - lane * 16 + (q31 & 15) * RPITCH + (q31 >> 4) * 512 + h2 * 16;     // this lane's row in the tile, + 16 B for h2
+    float *const obase = a.out + ((int64_t)batch * a.nq + r0 + 16 * h2) * D + 4 * q31;
+    auto e1_read = [&](auto ci, auto ni) __attribute__((always_inline)) {
+        constexpr int c = decltype(ci)::value, nb = decltype(ni)::value;
+        if constexpr (DBG & 16) return;
+        static_for<0, 4>([&](auto gi) {
+            constexpr int g = decltype(gi)::value;
+            lds_read<(32 * nb + 8 * g) * 4>(te[g], tq);
+            lds_read<(2 * D + 128 * c + 32 * nb + 8 * g) * 4>(te[4 + g], tb_addr);
+        });
+    };
+    auto e1_quarter = [&](auto ci, auto ni, auto gi) __attribute__((always_inline)) {
+        constexpr int c = decltype(ci)::value, nb = decltype(ni)::value, g = decltype(gi)::value;
+        if constexpr (DBG & 16) return;
+        if constexpr (g == 0) asm volatile("" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(te[5]), "+v"(te[6]), "+v"(te[7]));
+        f32x4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (oacc[c & 1][nb][4 * g + i] + te[4 + g][i]) + te[g][i];
+        lds_write<(32 * nb + 8 * g) * 4>(tq, o);
+    };
+    auto e2_read = [&](auto vi) __attribute__((always_inline)) {
+        constexpr int v4 = decltype(vi)::value;
+        if constexpr (DBG & 16) return;
+        static_for<0, 4>([&](auto ji) { lds_read<(4 * v4 + decltype(ji)::value) * RPITCH>(te[decltype(ji)::value], rs_addr); });
+    };
+    auto e2_store = [&](auto ci, auto vi, auto ji) __attribute__((always_inline)) {
+        constexpr int c = decltype(ci)::value, v4 = decltype(vi)::value, j = decltype(ji)::value;
+        if constexpr (DBG & 16) return;
+        if constexpr (j == 0) asm volatile("" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]));
+        if (active) __builtin_nontemporal_store(te[j], reinterpret_cast<f32x4 *>(obase + (int64_t)(4 * v4 + j) * D + 128 * c));
+    };
+    using CfgC = StepCfg<NCHUNK * NKS, true, false>;
+    static_for<0, NCHUNK>([&](auto ci) {
+        constexpr int c = decltype(ci)::value;
         static_for<0, NKS>([&](auto ki) {
-            constexpr int ks = decltype(ki)::value;
-            using Cfg = StepCfg<48, true, ks == NKS - 1>;
+            constexpr int ks = decltype(ki)::value, LB = NKS * c + ks;
             auto body = [&](h16x8(&f)[4], auto &&mid) __attribute__((always_inline)) {
+                auto vs = [&](auto si) __attribute__((always_inline)) {       // epilogue slices of chunk c - 1
+                    constexpr int sl = decltype(si)::value;
+                    if constexpr (c > 0 && ks < 16) {
+                        using CP = std::integral_constant<int, (c > 0 ? c - 1 : 0)>;
+                        constexpr int u = (ks % 8) / 2;
+                        if constexpr (ks < 8) {
+                            if constexpr (ks % 2 == 1) e1_quarter(CP{}, std::integral_constant<int, u>{}, si);
+                            else if constexpr (sl == 3) e1_read(CP{}, std::integral_constant<int, u>{});
+                        } else {
+                            if constexpr (ks % 2 == 1) e2_store(CP{}, std::integral_constant<int, u>{}, si);
+                            else if constexpr (sl == 3) e2_read(std::integral_constant<int, u>{});
+                        }
+                    }
+                };
                 static_for<0, NBC>([&](auto ni) {
                     constexpr int nb = decltype(ni)::value;
-                    if constexpr (ks == 0) acc[nb] = mfma_d(f[nb], qf[ks], zero);
-                    else acc[nb] = mfma_d(f[nb], qf[ks], acc[nb]);
+                    if constexpr (ks == 0) oacc[c & 1][nb] = mfma_d(f[nb], qf[ks], zero);
+                    else oacc[c & 1][nb] = mfma_d(f[nb], qf[ks], oacc[c & 1][nb]);
+                    vs(ni);
                     if constexpr (nb < 3) mid(std::integral_constant<int, nb>{});
                 });
-                if constexpr (ks == NKS - 1 && !(DBG & 16)) {
-                    // epilogue.  The residual pieces were requested >= 7 group ends ago, every ring wait since then covered them (vmcnt
-                    // is in order).  (1) out^T (lane = row, registers = columns) + bias is added INTO the residual tile in LDS, column-wise;
-                    // (2) the tile leaves row-wise: every store instruction writes two full 512-byte row segments.
-                    const uint32_t tq = rs_addr - lane * 16 + (q31 & 15) * RPITCH + (q31 >> 4) * 512 + h2 * 16;     // this lane's row, + 16 B for h2
-                    static_for<0, NBC>([&](auto ni) {
-                        constexpr int nb = decltype(ni)::value;
-                        f32x4 t[8];                              // t[g] residual, t[4 + g] bias, g = 0..3: columns 128 c + 32 nb + 8 g + 4 h2 .. + 3
-                        static_for<0, 4>([&](auto gi) {
-                            constexpr int g = decltype(gi)::value;
-                            lds_read<(32 * nb + 8 * g) * 4>(t[g], tq);
-                            lds_read<(32 * nb + 8 * g) * 4>(t[4 + g], tbo);
-                        });
-                        lds_wait0(t);
-                        static_for<0, 4>([&](auto gi) {
-                            constexpr int g = decltype(gi)::value;
-                            f32x4 o;
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) o[i] = (acc[nb][4 * g + i] + t[4 + g][i]) + t[g][i];
-                            lds_write<(32 * nb + 8 * g) * 4>(tq, o);
-                        });
-                        __builtin_amdgcn_sched_barrier(0);
-                    });
-                    float *ob = a.out + ((int64_t)batch * a.nq + r0 + 16 * h2) * D + 128 * c + 4 * q31;
-                    static_for<0, 4>([&](auto vi) {
-                        constexpr int v4 = decltype(vi)::value;
-                        f32x4 t[4];
-                        static_for<0, 4>([&](auto ji) { lds_read<(4 * v4 + decltype(ji)::value) * RPITCH>(t[decltype(ji)::value], rs_addr); });
-                        lds_wait0(t);
-                        if (active) {
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) __builtin_nontemporal_store(t[j], reinterpret_cast<f32x4 *>(ob + (int64_t)(4 * v4 + j) * D));
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    });
-                }
             };
-            if constexpr (ks % 2 == 0) step_impl(std::integral_constant<int, ks>{}, Cfg{}, false, c == NCHUNK - 1, c, FA, FB, body);
-            else step_impl(std::integral_constant<int, ks>{}, Cfg{}, false, c == NCHUNK - 1, c, FB, FA, body);
+            if constexpr (LB % 2 == 0) step_impl(std::integral_constant<int, LB>{}, CfgC{}, false, true, c, FA, FB, body);
+            else step_impl(std::integral_constant<int, LB>{}, CfgC{}, false, true, c, FB, FA, body);
         });
-    }
+    });
+    // the last chunk's epilogue has nothing left to hide under
+    static_for<0, NBC>([&](auto ni) {
+        e1_read(std::integral_constant<int, NCHUNK - 1>{}, ni);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3]), "+v"(te[4]), "+v"(te[5]), "+v"(te[6]), "+v"(te[7])::"memory");
+        static_for<0, 4>([&](auto gi) { e1_quarter(std::integral_constant<int, NCHUNK - 1>{}, ni, gi); });
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    static_for<0, 4>([&](auto vi) {
+        e2_read(vi);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(te[0]), "+v"(te[1]), "+v"(te[2]), "+v"(te[3])::"memory");
+        static_for<0, 4>([&](auto ji) { e2_store(std::integral_constant<int, NCHUNK - 1>{}, vi, ji); });
+        __builtin_amdgcn_sched_barrier(0);
+    });
     stamp(5);
 }
 
