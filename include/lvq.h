@@ -291,7 +291,13 @@ int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_
  *       scratch of the call: a list that is used has fewer than n_tiles tiles).
  *   lvq_attention_bf16_tiled_signed: as lvq_attention_bf16_tiled (same q as the totals; q_bstride = 0 shares one copy).  A
  *       (batch, head) whose signed row sum is not finite or below 1/16 of the table total is redone over its full stream by a
- *       predicated second launch.  Not bit-identical to the full stream (fp32 accumulation order); same operand roundings. */
+ *       predicated second launch.  Not bit-identical to the full stream (fp32 accumulation order); same operand roundings -- EXCEPT with
+ *       k_fp16 ("mixed16"): the totals may have been taken with the full query (k_fp16 = 2: fp16 hi + lo, the default of the Python mirror)
+ *       while the per-scene streams subtract the table rows with the once-rounded fp16 query, so the subtraction cancels only up to that
+ *       rounding (2^-11 of each subtracted score; grows with the dirty fraction, < 50 % by construction).  Deliberate: the clean 70 % of
+ *       the keys then never see the rounded query (5.6e-4 -> 2.8e-4 on the bench scene); pass k_fp16 = 1 to the totals for exact
+ *       cancellation.  The 1/16 trigger above was derived for fp32 ordering error only and is not a bound for this mode: mixed16 is
+ *       held to the 1e-3 bar by tests (tests/test_gpu_tiled_stream.py, tests/test_gpu_pipeline.py), not by that trigger. */
 size_t lvq_attention_stream_totals_workspace_bytes(int n_heads, int nq, int nkv, int dh);
 int lvq_attention_bf16_stream_totals(const lvq_bf16 *q, const lvq_bf16 *q_lo, const lvq_bf16 *k, const lvq_bf16 *v, int n_heads, int nq,
                                      int nkv, int dh, int64_t ldq, int64_t q_hstride, int64_t ldkv, int64_t kv_hstride, float scale, int k_fp16,

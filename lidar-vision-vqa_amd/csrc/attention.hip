@@ -1658,7 +1658,9 @@ extern "C" int lvq_attention_bf16_tiled(const lvq_bf16 *q, const lvq_bf16 *q_lo,
 // all table keys (once per model: lvq_attention_bf16_stream_totals), a batch's result is
 //     TOTALS - sum over its live positions of the table contribution + sum over its live rows,
 // i.e. a stream over 2 x (live fraction) of the keys instead of all of them.  The subtracted terms are recomputed with the same
-// operand bits as inside TOTALS, so the cancellation is exact up to fp32 accumulation order.  Batches whose pair list would not be
+// operand bits as inside TOTALS, so the cancellation is exact up to fp32 accumulation order (not in the mixed16 mode when the totals
+// were taken with the full fp16 hi + lo query, k_fp16 = 2: there the per-scene streams subtract with the once-rounded query and the
+// cancellation holds to 2^-11 of the subtracted scores only -- deliberate, see include/lvq.h).  Batches whose pair list would not be
 // shorter run their full tile list; (batch, head) pairs whose signed result is unusable are redone by a predicated full launch.
 
 // totals [n_heads, nq, dh + 2] fp32 (unnormalised O | m | l) of ONE batch of queries over a dense key stream (the table).

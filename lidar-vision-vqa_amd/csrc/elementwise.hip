@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(256) k_cross_entropy(const float *__restrict__
 // TopKLogitsWarper -> TopPLogitsWarper -> softmax -> one multinomial draw per row.
 //   * top-k keeps every logit >= the k-th largest (ties stay, as `scores < topk(scores, k)[0][..., -1]` removes only smaller
 //     ones): the threshold is found by a 4-pass radix select on the order-preserving uint image of the floats (no sort of the
-//     vocabulary), the survivors (<= SAMPLE_CAP) are collected into LDS and bitonic-sorted descending (ties: lower id first);
+//     vocabulary), the survivors (<= SAMPLE_CAP; beyond it, ties at the k-th value are kept in ascending index order) are collected into LDS and bitonic-sorted descending (ties: lower id first);
 //   * top-p keeps token j iff the probability mass ranked strictly before it is < top_p (the descending-order statement of
 //     `cumsum(softmax(sorted ascending)) <= 1 - top_p` is removed; at least one token stays);
 //   * the draw is the inverse CDF at the caller's uniform u in [0, 1) over the kept, renormalised probabilities.
@@ -511,15 +511,57 @@ __global__ void __launch_bounds__(SAMPLE_NT) k_sample_rows(const float *__restri
         __syncthreads();
     }
     const uint32_t kth = sh_prefix;                         // every element with key >= kth survives top-k
-    // ---- collect the survivors ----
+    // ---- collect the survivors: everything STRICTLY above the k-th key first (at most top_k - 1 <= 1023 entries, order irrelevant: they
+    // are sorted below), then the ties at the k-th key.  If strict + ties fit the cap (the common case: one tie), the ties are collected
+    // the same way; otherwise (mass ties: a constant or clamped row) the ties are taken in ASCENDING INDEX order up to the cap, so the
+    // kept set is a function of the logits alone (never of the atomics' arrival order) and no larger logit is ever displaced by a tie ----
     for (int i = tid; i < SAMPLE_CAP; i += SAMPLE_NT) { c_val[i] = -INFINITY; c_idx[i] = 0x7fffffff; }
+    if (tid == 0) sh_keep = 0;                              // (re-used: number of ties)
     __syncthreads();
     for (int i = tid; i < vocab; i += SAMPLE_NT) {
         const float v = x[i];
-        if (f32_order_key(v) >= kth) {
+        const uint32_t k = f32_order_key(v);
+        if (k > kth) {
             const int q = atomicAdd(&sh_count, 1);
-            if (q < SAMPLE_CAP) { c_val[q] = v; c_idx[q] = i; }
+            c_val[q] = v; c_idx[q] = i;
+        } else if (k == kth) {
+            atomicAdd(&sh_keep, 1);
         }
+    }
+    __syncthreads();
+    const int n_strict = sh_count, n_ties = sh_keep;
+    __syncthreads();
+    if (n_strict + n_ties <= SAMPLE_CAP) {
+        for (int i = tid; i < vocab; i += SAMPLE_NT) {
+            const float v = x[i];
+            if (f32_order_key(v) == kth) {
+                const int q = atomicAdd(&sh_count, 1);
+                c_val[q] = v; c_idx[q] = i;
+            }
+        }
+    } else {
+        // ordered pass: chunk by chunk in index order, a tie's slot = ties before it (block-wide exclusive count)
+        int placed = n_strict;
+        for (int base = 0; base < vocab && placed < SAMPLE_CAP; base += SAMPLE_NT) {
+            const int i = base + tid;
+            const float v = i < vocab ? x[i] : 0.f;
+            const bool tie = i < vocab && f32_order_key(v) == kth;
+            const unsigned long long bal = __ballot(tie);
+            const int lane_ = tid & 63, w_ = tid >> 6;
+            if (lane_ == 0) wsum[w_] = (float)__popcll(bal);
+            __syncthreads();
+            int before = 0, total_c = 0;
+            for (int w = 0; w < SAMPLE_NT / 64; ++w) {
+                const int c = (int)wsum[w];
+                if (w < w_) before += c;
+                total_c += c;
+            }
+            const int slot = placed + before + __popcll(bal & ((1ull << lane_) - 1ull));
+            if (tie && slot < SAMPLE_CAP) { c_val[slot] = v; c_idx[slot] = i; }
+            placed += total_c;
+            __syncthreads();
+        }
+        if (tid == 0) sh_count = placed < SAMPLE_CAP ? placed : SAMPLE_CAP;
     }
     __syncthreads();
     const int n = sh_count < SAMPLE_CAP ? sh_count : SAMPLE_CAP;

@@ -286,6 +286,18 @@ def test_sample_rows_edge_cases():
     ids = ops.sample_rows(flat, 1.0, 5, 1.0, torch.Generator(device=DEV).manual_seed(3)).cpu()
     cnt = torch.bincount(ids, minlength=300)
     assert int(cnt.min()) > 20 and int(cnt.max()) < 140
+    # more survivors than the kernel's 2048 candidate slots (a constant row of 5000 logits: every logit ties at the k-th value, plus three
+    # larger ones): the larger logits are never displaced by ties, the ties are kept in ascending index order (ids 0 .. 2044), and the draw
+    # is reproducible under a fixed generator (collection order used to be the atomics' arrival order)
+    wide = torch.zeros(4000, 5000, device=DEV)
+    wide[:, [4100, 4500, 4999]] = 1.0
+    g1 = ops.sample_rows(wide, 1.0, 50, 1.0, torch.Generator(device=DEV).manual_seed(11)).cpu()
+    g2 = ops.sample_rows(wide, 1.0, 50, 1.0, torch.Generator(device=DEV).manual_seed(11)).cpu()
+    assert torch.equal(g1, g2)
+    big = (g1 == 4100) | (g1 == 4500) | (g1 == 4999)
+    assert bool(((g1 < 2045) | big).all()) and int(big.sum()) > 0 and int((g1[~big]).max()) > 1900
+    frac = float(big.float().mean())                                    # 3 e / (3 e + 2045) = 0.398 %
+    assert 0.001 < frac < 0.01, frac
     with pytest.raises(_ffi.LvqError):
         ops.sample_rows(x, 0.7, 0, 0.9)                                 # top-k disabled on a 151 936-wide row: not supported
     with pytest.raises(_ffi.LvqError):
