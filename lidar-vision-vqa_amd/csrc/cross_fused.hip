@@ -344,9 +344,11 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
         auto mid = [&](auto mi) __attribute__((always_inline)) {
             constexpr int m = decltype(mi)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (m < 2 && !LATE && !(DBG & 4)) {
-                lds_read<nbase + 2 * m * FRAG>(nxt[2 * m], fr_addr);
-                lds_read<nbase + (2 * m + 1) * FRAG>(nxt[2 * m + 1], fr_addr);
+            if constexpr (m == 0 && !LATE && !(DBG & 4)) {                        // all four right behind the first MFMA: three MFMAs of cover
+                lds_read<nbase>(nxt[0], fr_addr);
+                lds_read<nbase + FRAG>(nxt[1], fr_addr);
+                lds_read<nbase + 2 * FRAG>(nxt[2], fr_addr);
+                lds_read<nbase + 3 * FRAG>(nxt[3], fr_addr);
             }
             if constexpr (m == 2) {
                 constexpr int u = (LB + 13) % 16;                                 // piece u % 4 of the group that takes slot u / 4
