@@ -14,7 +14,9 @@
  *   - every pointer is a DEVICE pointer unless the parameter comment says "host".
  *   - the caller owns every buffer, including the workspace whose size is queried first;
  *     nothing is allocated, freed or synchronised inside a call -> stream-ordered, asynchronous,
- *     graph-capturable, no global state (thread-safe per stream).
+ *     graph-capturable, thread-safe per stream.  The library never reads the environment; its only process-wide state is the
+ *     tuning record below (kernel-family choices and test hooks), which the caller sets explicitly (lvq_set_tuning) and which
+ *     changes speed or the kernel family, never results beyond what each field documents.
  *   - return value: LVQ_OK (0) or a negative LVQ_E* code; never throws, never exits.
  *   - rows are contiguous, row-major; "bf16" is the upper 16 bits of an IEEE fp32 (uint16_t).
  */
@@ -42,6 +44,34 @@ enum {
 
 const char *lvq_version(void);
 const char *lvq_strerror(int code);
+
+/* Kernel-family choices that are not implied by the shapes: every routing decision that used to hide behind a getenv inside the library
+ * (VERDICT r2).  All zeros = the built-in choices (lvq_tuning_defaults).  Process-wide: set it before launching, not concurrently with
+ * launches of other threads.  The Python mirror fills it from the LVQ_* environment variables of INTEGRATION.md (lidar-vision-vqa_amd/_ffi.py);
+ * all variants of one entry point are held to the same oracle by the tests. */
+typedef struct lvq_tuning {
+    int32_t attn_no32;               /* 1: the 16x16x32 attention kernel for long K/V streams instead of k_attn32 */
+    int32_t attn32_nw;               /* k_attn32 waves per workgroup: 0 auto, 4 or 6 */
+    int32_t attn_pipe;               /* k_attn32 with 4 waves: 0 auto (pipelined for hi + lo / fp16 queries), 1 always pipelined, -1 never */
+    int32_t attn_nsplit;             /* KV split count of the attention kernels: 0 auto, 1..64 (test hook: 1 = direct output path) */
+    int32_t attn_qt;                 /* k_attn query tiles per wave: 0 auto, 1, 2 or 4 */
+    int32_t attn_nw;                 /* k_attn waves per workgroup: 0 auto, 4, 8 or 12 */
+    int32_t gemm_no_gemv;            /* 1: MFMA tile kernels also for M <= 8 (instead of the skinny-M GEMV) */
+    int32_t gemm_stream_c_mb;        /* output size (MB) from which GEMM outputs use non-temporal stores: 0 = 32, -1 = never */
+    int32_t gemm_no256;              /* 1: no 8-wave 256x128 / 256x256 GEMM kernels (128x128 tiles) */
+    int32_t gemm_no256x256;          /* 1: no 256x256 GEMM kernel */
+    int32_t gemm_256x256_min_tiles;  /* tile count from which the 256x256 kernel is used: 0 = 1024 or one full dispatch round */
+    int32_t gemm_ln_tiles;           /* 1: tile kernel instead of the row-streaming Linear + LayerNorm kernel */
+    int32_t pillar_vfe_generic;      /* 1: generic multi-layer PillarVFE kernel instead of the single-layer one */
+    int32_t voxel_path;              /* hard / dynamic voxeliser: 0 default (hash-balanced slabs / slab-binned), 1 slab-binned, 2 global hash / two-level bitmap */
+    int32_t pairs_one_wg;            /* 1: lvq_bev_scene_pairs with one workgroup per scene */
+    int32_t ca_fused_variant;        /* diagnostics builds (CA_DEBUG_VARIANTS) only: timing-ablation variant of k_ca_fused; results are wrong */
+    uint64_t ca_fused_stamps;        /* diagnostics: device pointer to [workgroups][4][8] uint64 that k_ca_fused fills with s_memrealtime stamps, or 0 */
+    int32_t reserved[8];
+} lvq_tuning;
+void lvq_tuning_defaults(lvq_tuning *t);
+int lvq_set_tuning(const lvq_tuning *t);      /* NULL restores the defaults */
+int lvq_get_tuning(lvq_tuning *t);
 
 /* =====================================================================================
  * LiDAR side

@@ -28,6 +28,90 @@ class LvqError(RuntimeError):
 _lib: Optional[ctypes.CDLL] = None
 
 
+class Tuning(ctypes.Structure):
+    """include/lvq.h: lvq_tuning -- the kernel-family choices the library takes from its caller (it never reads the environment)."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "attn_no32", "attn32_nw", "attn_pipe", "attn_nsplit", "attn_qt", "attn_nw", "gemm_no_gemv", "gemm_stream_c_mb", "gemm_no256",
+        "gemm_no256x256", "gemm_256x256_min_tiles", "gemm_ln_tiles", "pillar_vfe_generic", "voxel_path", "pairs_one_wg",
+        "ca_fused_variant")] + [("ca_fused_stamps", ctypes.c_uint64), ("reserved", ctypes.c_int32 * 8)]
+
+
+TUNING_FIELDS = tuple(n for n, _ in Tuning._fields_ if n != "reserved")
+
+
+def tuning_from_env(env=None) -> dict:
+    """The LVQ_* variables of INTEGRATION.md as an lvq_tuning record.  They are a convenience of THIS mirror, read once when the
+    library is loaded (and again by set_tuning()); a C / C++ caller fills the struct itself."""
+    e = os.environ if env is None else env
+
+    def flag(name):
+        return 1 if e.get(name) else 0
+
+    def num(name):
+        return int(e[name]) if e.get(name) else 0
+
+    return {
+        "attn_no32": flag("LVQ_ATTN_NO32"), "attn32_nw": num("LVQ_ATTN32_NW"),
+        "attn_pipe": -1 if e.get("LVQ_ATTN_NO_PIPE") else flag("LVQ_ATTN_PIPE"),
+        "attn_nsplit": num("LVQ_ATTN_NSPLIT"), "attn_qt": num("LVQ_ATTN_QT"), "attn_nw": num("LVQ_ATTN_NW"),
+        "gemm_no_gemv": flag("LVQ_GEMM_NO_GEMV"),
+        "gemm_stream_c_mb": -1 if e.get("LVQ_GEMM_NO_STREAM_C") else num("LVQ_GEMM_STREAM_C_MB"),
+        "gemm_no256": flag("LVQ_GEMM_NO256"), "gemm_no256x256": flag("LVQ_GEMM_NO256X256"),
+        "gemm_256x256_min_tiles": num("LVQ_GEMM_256X256_MIN_TILES"), "gemm_ln_tiles": flag("LVQ_GEMM_LN_TILES"),
+        "pillar_vfe_generic": flag("LVQ_PILLAR_VFE_GENERIC"),
+        "voxel_path": 2 if e.get("LVQ_VOXEL_LEGACY") else flag("LVQ_VOXEL_BINNED"),
+        "pairs_one_wg": flag("LVQ_PAIRS_ONE_WG"), "ca_fused_variant": num("LVQ_CA_DBG"), "ca_fused_stamps": 0,
+    }
+
+
+def set_tuning(**fields) -> dict:
+    """lvq_set_tuning: the record implied by the environment, overridden by `fields` (names of include/lvq.h: lvq_tuning).
+    set_tuning() with no arguments restores the environment's choices.  Returns the record now in force."""
+    rec = tuning_from_env()
+    for k, v in fields.items():
+        if k not in TUNING_FIELDS:
+            raise LvqError(f"lvq_tuning has no field {k!r}")
+        rec[k] = int(v)
+    t = Tuning()
+    for k, v in rec.items():
+        setattr(t, k, v)
+    check(lib().lvq_set_tuning(ctypes.byref(t)), "lvq_set_tuning")
+    return rec
+
+
+def get_tuning() -> dict:
+    t = Tuning()
+    check(lib().lvq_get_tuning(ctypes.byref(t)), "lvq_get_tuning")
+    return {k: int(getattr(t, k)) for k in TUNING_FIELDS}
+
+
+class tuning:
+    """`with tuning(attn_nsplit=1): ...` -- a kernel-family choice for the calls inside (process-wide: not for concurrent launch threads)."""
+
+    def __init__(self, **fields):
+        self.fields = fields
+
+    def __enter__(self):
+        self.old = get_tuning()
+        cur = dict(self.old)
+        cur.update({k: int(v) for k, v in self.fields.items()})
+        _push(cur)
+        return self
+
+    def __exit__(self, *exc):
+        _push(self.old)
+        return False
+
+
+def _push(rec: dict):
+    t = Tuning()
+    for k, v in rec.items():
+        if k not in TUNING_FIELDS:
+            raise LvqError(f"lvq_tuning has no field {k!r}")
+        setattr(t, k, v)
+    check(lib().lvq_set_tuning(ctypes.byref(t)), "lvq_set_tuning")
+
+
 def declared_symbols() -> List[str]:
     """Every function name declared in include/lvq.h (used by the export test and INTEGRATION.md)."""
     with open(HEADER_PATH) as f:
@@ -53,7 +137,9 @@ def lib() -> ctypes.CDLL:
                      "lvq_attention_stream_totals_workspace_bytes", "lvq_attention_tiled_signed_workspace_bytes",
                      "lvq_bev_tile_kv_workspace_bytes", "lvq_ca_fused_packed_bytes", "lvq_ca_fused_workspace_bytes"):
             getattr(L, name).restype = ctypes.c_size_t
+        L.lvq_tuning_defaults.restype = None
         _lib = L
+        _push(tuning_from_env())               # the library itself never reads the environment (include/lvq.h: lvq_tuning)
     return _lib
 
 

@@ -14,3 +14,20 @@ extern "C" const char *lvq_strerror(int code) {
         default: return "unknown error";
     }
 }
+
+// ---- the tuning record (include/lvq.h): the library's only process-wide state, set explicitly by the caller ----
+static lvq_tuning g_tuning = {};
+const lvq_tuning &lvq_tune() { return g_tuning; }
+
+extern "C" void lvq_tuning_defaults(lvq_tuning *t) {
+    if (t) *t = lvq_tuning{};
+}
+extern "C" int lvq_set_tuning(const lvq_tuning *t) {
+    g_tuning = t ? *t : lvq_tuning{};
+    return LVQ_OK;
+}
+extern "C" int lvq_get_tuning(lvq_tuning *t) {
+    if (!t) return LVQ_EINVAL;
+    *t = g_tuning;
+    return LVQ_OK;
+}

@@ -1323,8 +1323,8 @@ __global__ void __launch_bounds__(256) k_attn_combine_raw(AttnArgs a, float *__r
 struct AttnPlan { int qt, nw, nqt, nsplit, k32; };
 // k_attn32 geometry (0 = not applicable): 32 queries per wave, 4 or 6 waves, at most 1/8 of the query slots padding
 int plan_k32_waves(int nq, int nkv, int dh, bool split) {      // split = K / V carry lo parts (full bf16x3): not this kernel
-    if (split || dh != 64 || nkv < 4096 || (nkv % KVB) != 0 || getenv("LVQ_ATTN_NO32") != nullptr) return 0;
-    const int force = getenv("LVQ_ATTN32_NW") ? atoi(getenv("LVQ_ATTN32_NW")) : 0;
+    if (split || dh != 64 || nkv < 4096 || (nkv % KVB) != 0 || lvq_tune().attn_no32) return 0;
+    const int force = lvq_tune().attn32_nw;
     for (int nw : {4, 6}) {       // measured on 576 x 262144: 4 waves 2.29 ms, 6 waves 2.63, 3 waves 2.71 (three workgroups per CU at 4)
         if (force && nw != force) continue;
         const int64_t tile = 32 * nw, padded = (nq + tile - 1) / tile * tile;
@@ -1338,8 +1338,8 @@ int plan_k32_waves(int nq, int nkv, int dh, bool split) {      // split = K / V 
 // hide behind) the two forms measure within 2 % of each other either way and the 3-waves-per-SIMD form stays.  LVQ_ATTN_NO_PIPE=1 / LVQ_ATTN_PIPE=1 force one form for every
 // query kind (A/B: tools/ab_attn_pipe.py; DESIGN 3.2 has the measurements)
 bool k32_pipe(int nw, int qs) {
-    if (nw != 4 || getenv("LVQ_ATTN_NO_PIPE") != nullptr) return false;
-    return qs != 0 || getenv("LVQ_ATTN_PIPE") != nullptr;
+    if (nw != 4 || lvq_tune().attn_pipe < 0) return false;
+    return qs != 0 || lvq_tune().attn_pipe > 0;
 }
 AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, bool allow32 = false, int qs = 0) {
     AttnPlan p;
@@ -1367,8 +1367,8 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, 
             }
             ns = best_ns;
         }
-        if (const char *ev = getenv("LVQ_ATTN_NSPLIT")) {       // test hook: force the KV split count (1 = direct output path)
-            const int f = atoi(ev);
+        if (lvq_tune().attn_nsplit) {       // test hook: force the KV split count (1 = direct output path)
+            const int f = lvq_tune().attn_nsplit;
             if (f >= 1 && f <= 64 && f <= n_tiles) ns = f;
         }
         p.nsplit = ns;
@@ -1381,8 +1381,8 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, 
     // resident) beats 2 or 4 tiles per wave on every shape tried -- occupancy hides the softmax VALU and the
     // staging latency better than K/V fragment reuse saves LDS reads.
     p.qt = (dhp >= 96 && !split) ? 2 : 1;             // head_dim 96/128: two tiles per wave measured faster (377 vs 267 TFLOP/s)
-    if (const char *ev = getenv("LVQ_ATTN_QT")) {      // tuning knob (tools/bench_kernels.py); not used in production
-        const int f = atoi(ev);
+    if (lvq_tune().attn_qt) {      // tuning knob (tools/bench_kernels.py); not used in production
+        const int f = lvq_tune().attn_qt;
         if ((f == 1 || f == 2 || f == 4) && f <= qmax) p.qt = f;
     }
     // waves per workgroup: long K/V streams are bandwidth-bound on re-reads -> as many queries per stream as fit
@@ -1393,8 +1393,8 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, 
             if ((padded - nq) * 8 <= nq) { p.nw = nw; break; }
         }
     }
-    if (const char *ev = getenv("LVQ_ATTN_NW")) {
-        const int f = atoi(ev);
+    if (lvq_tune().attn_nw) {
+        const int f = lvq_tune().attn_nw;
         if ((f == 4 || f == 8 || f == 12) && p.qt == 1 && dhp <= 64) p.nw = f;
     }
     p.nqt = (nq + 16 * p.nw * p.qt - 1) / (16 * p.nw * p.qt);
@@ -1417,8 +1417,8 @@ AttnPlan plan_attn(int batch, int n_heads, int nq, int nkv, int dh, bool split, 
     }
     if (ns < 1) ns = 1;
     if (ns > 64) ns = 64;
-    if (const char *ev = getenv("LVQ_ATTN_NSPLIT")) {           // test / tuning hook, as for k_attn32
-        const int f = atoi(ev);
+    if (lvq_tune().attn_nsplit) {           // test / tuning hook, as for k_attn32
+        const int f = lvq_tune().attn_nsplit;
         if (f >= 1 && f <= 64 && f <= n_tiles) ns = f;
     }
     p.nsplit = ns;

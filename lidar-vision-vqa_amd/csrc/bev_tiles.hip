@@ -1465,7 +1465,7 @@ extern "C" int lvq_bev_scene_pairs(const int32_t *row_src, int batch, int n_tile
                                    int32_t *pair_info, lvq_stream_t stream) {
     if (!row_src || !pair_src || !pair_info || batch <= 0 || n_tiles <= 0 || cap_tiles <= 0 || row_base < 0) return LVQ_EINVAL;
     if (((uintptr_t)row_src & 15) || (int64_t)n_tiles * bt::TCELLS > 0x7fffffff || batch > 65535) return LVQ_EUNSUPPORTED;
-    if (cap_tiles >= n_tiles && cap_tiles >= 2 && getenv("LVQ_PAIRS_ONE_WG") == nullptr) {
+    if (cap_tiles >= n_tiles && cap_tiles >= 2 && !lvq_tune().pairs_one_wg) {
         // many workgroups per scene: <= 64 chunks of whole 1024-word rounds; the chunk counts use the list's last tile slot as scratch
         const int64_t ne = (int64_t)n_tiles * bt::TCELLS;
         int64_t chunk = (ne + 63) / 64;

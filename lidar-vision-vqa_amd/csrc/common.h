@@ -8,6 +8,9 @@
 
 #define LVQ_WAVE 64
 
+// the tuning record (api.hip): kernel-family choices set through lvq_set_tuning; the library never reads the environment
+const lvq_tuning &lvq_tune();
+
 static inline hipStream_t lvq_s(lvq_stream_t s) { return (hipStream_t)s; }
 
 // every entry point ends with this: launch errors become a return code, never an abort

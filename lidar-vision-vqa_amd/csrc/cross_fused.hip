@@ -897,18 +897,12 @@ template <int DBG> void launch_dbg(const CaArgs &a, int64_t nwg, hipStream_t st)
 #endif
 template <bool F16> int launch_fused(const CaArgs &a, int kc, int64_t nwg, hipStream_t st) {
 #ifdef CA_DEBUG_VARIANTS
-    if (const char *e = getenv("LVQ_CA_DBG")) {
-        switch (atoi(e)) {
-            case 1: launch_dbg<1>(a, nwg, st); return LVQ_OK;
+    if (lvq_tune().ca_fused_variant) {
+        switch (lvq_tune().ca_fused_variant) {
             case 2: launch_dbg<2>(a, nwg, st); return LVQ_OK;
-            case 4: launch_dbg<4>(a, nwg, st); return LVQ_OK;
             case 8: launch_dbg<8>(a, nwg, st); return LVQ_OK;
+            case 10: launch_dbg<10>(a, nwg, st); return LVQ_OK;
             case 16: launch_dbg<16>(a, nwg, st); return LVQ_OK;
-            case 6: launch_dbg<6>(a, nwg, st); return LVQ_OK;
-            case 14: launch_dbg<14>(a, nwg, st); return LVQ_OK;
-            case 30: launch_dbg<30>(a, nwg, st); return LVQ_OK;
-            case 31: launch_dbg<31>(a, nwg, st); return LVQ_OK;
-            case 29: launch_dbg<29>(a, nwg, st); return LVQ_OK;
         }
     }
 #endif
@@ -987,10 +981,7 @@ extern "C" int lvq_ca_fused(const float *q, const float *kv, const void *packed,
     a.kv_batch_bytes = (int64_t)NH * cf * FRAG;
     a.eps = eps;
     a.qscale = QSCALE;
-    {
-        const char *e = getenv("LVQ_CA_STAMPS");          // diagnostics: a device pointer (decimal) to [workgroups][4][8] uint64
-        a.stamps = e ? (unsigned long long *)strtoull(e, nullptr, 10) : nullptr;
-    }
+    a.stamps = (unsigned long long *)(uintptr_t)lvq_tune().ca_fused_stamps;     // diagnostics (include/lvq.h: lvq_tuning)
     const int64_t nwg = (int64_t)batch * a.tiles_per_batch;
     const int rc = f16 ? launch_fused<true>(a, kc, nwg, st) : launch_fused<false>(a, kc, nwg, st);
     if (rc != LVQ_OK) return rc;

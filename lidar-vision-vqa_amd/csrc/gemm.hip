@@ -1217,7 +1217,7 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
     if ((k & 7) || (lda & 7) || (ldw & 7) || (a_bs & 7) || (w_bs & 7) || lda < k || ldw < k || ldc < n)
         return LVQ_EUNSUPPORTED;
     if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)a_lo | (uintptr_t)w_lo) & 15) return LVQ_EUNSUPPORTED;
-    if (m <= 8 && batch == 1 && n >= 64 && (a_lo != nullptr || w_lo == nullptr) && getenv("LVQ_GEMM_NO_GEMV") == nullptr) {   // skinny M: stream W once (k_gemv)
+    if (m <= 8 && batch == 1 && n >= 64 && (a_lo != nullptr || w_lo == nullptr) && !lvq_tune().gemm_no_gemv) {   // skinny M: stream W once (k_gemv)
         launch_gemv<0>(a_lo != nullptr, lvq_s(stream), a, a_lo, w, w_lo, bias, residual, rowtab, rowtab_rows, alpha, (flags & LVQ_GEMM_GELU) != 0,
                            (int)m, n, k, lda, ldw, ldc, c_f32, c_bf16, c_lo, nullptr, nullptr, 0.f);
         return lvq_launch_status();
@@ -1237,9 +1237,9 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
     // the Infinity Cache; neutral on the full pipeline, whose big projections stream already.
     {
         const int64_t c_bytes = (int64_t)m * n * batch * ((c_f32 ? 4 : 0) + (c_bf16 ? 2 : 0) + (c_lo ? 2 : 0));
-        const char *ev = getenv("LVQ_GEMM_STREAM_C_MB");
-        const int64_t thr = (ev ? atoll(ev) : 32) << 20;
-        g.stream_c = c_bytes >= thr && getenv("LVQ_GEMM_NO_STREAM_C") == nullptr;
+        const int mb = lvq_tune().gemm_stream_c_mb;
+        const int64_t thr = (int64_t)(mb > 0 ? mb : 32) << 20;
+        g.stream_c = c_bytes >= thr && mb >= 0;
     }
     g.vec_epilogue = (n % 8 == 0) && (ldc % 8 == 0) && (c_bs % 8 == 0) &&
                      !(((uintptr_t)c_f32 | (uintptr_t)residual | (uintptr_t)bias | (uintptr_t)rowtab) & 15) &&
@@ -1249,18 +1249,18 @@ extern "C" int lvq_gemm_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_
     const bool dma = (k % 64) == 0;      // LDS-DMA path needs whole 64-wide K tiles (no per-chunk zero fill)
     const bool ge = (flags & LVQ_GEMM_GELU) != 0;
     // 256x128 / 8 waves / 3 stages when there is enough work to fill the chip with the bigger tile
-    const bool huge = dma && lvq_cdiv(m, 256) * lvq_cdiv(n, 128) * batch >= 512 && getenv("LVQ_GEMM_NO256") == nullptr;
+    const bool huge = dma && lvq_cdiv(m, 256) * lvq_cdiv(n, 128) * batch >= 512 && !lvq_tune().gemm_no256;
     if (batch > 65535) return LVQ_EUNSUPPORTED;
     // 256x256 / two 64-KiB slots: 2/3 of the L2->LDS fill bytes of the 256x128 tile (the bound on these projections);
     // whole tiles only, and enough of them that the coarser grid still fills the 256 CUs several times over
     static LvqLdsOnce once256;      // per device: did the runtime grant 160 KiB of dynamic LDS?
     // ... or, below that, when one tile per CU keeps >= 80 % of the CUs of its last dispatch round busy (18432 x 768: 216 tiles in one
     // round, 0.150 -> ~0.1 ms per x3 GEMM of the query side; 260 tiles would be two rounds for four tiles and stay on the smaller kernels)
-    static const int64_t min256 = getenv("LVQ_GEMM_256X256_MIN_TILES") ? atoll(getenv("LVQ_GEMM_256X256_MIN_TILES")) : 1024;
+    const int64_t min256 = lvq_tune().gemm_256x256_min_tiles > 0 ? lvq_tune().gemm_256x256_min_tiles : 1024;
     const int64_t t256 = (m / 256) * (n / 256) * batch, cus = lvq_cu_count();
     const bool round_ok = t256 >= 200 && t256 * 5 >= ((t256 + cus - 1) / cus) * cus * 4;
-    if (dma && g.vec_epilogue && m % 256 == 0 && n % 256 == 0 && (t256 >= min256 || (round_ok && getenv("LVQ_GEMM_256X256_MIN_TILES") == nullptr)) &&
-        (m / 256) * (n / 256) <= 0x7fffffff && getenv("LVQ_GEMM_NO256X256") == nullptr && getenv("LVQ_GEMM_NO256") == nullptr) {
+    if (dma && g.vec_epilogue && m % 256 == 0 && n % 256 == 0 && (t256 >= min256 || (round_ok && lvq_tune().gemm_256x256_min_tiles <= 0)) &&
+        (m / 256) * (n / 256) <= 0x7fffffff && !lvq_tune().gemm_no256x256 && !lvq_tune().gemm_no256) {
         const size_t lds = (size_t)5 * 256 * 128;              // A ring 3 x 32 KiB + W ring 2 x 32 KiB
         if (lvq_ensure_lds(once256, {(const void *)k_gemm_256<0, 0>, (const void *)k_gemm_256<1, 0>, (const void *)k_gemm_256<0, 1>,
                                      (const void *)k_gemm_256<1, 1>}, lds)) {
@@ -1367,7 +1367,7 @@ extern "C" int lvq_gemm_ln_bf16(const lvq_bf16 *a, const lvq_bf16 *a_lo, const l
         g.scenes = (int)(m / post_rows);            // whole tiles per scene, tiles-per-scene a multiple of the 8 XCDs
     hipStream_t st = lvq_s(stream);
     // K = 64, plain bf16, table rows aligned to scenes: the row-streaming kernel (W resident in LDS, table read once)
-    if (g.nseg == 1 && k == 64 && n % 64 == 0 && n <= 1024 && lvq_cdiv(m, 16) <= 0x7fffffff && getenv("LVQ_GEMM_LN_TILES") == nullptr &&
+    if (g.nseg == 1 && k == 64 && n % 64 == 0 && n <= 1024 && lvq_cdiv(m, 16) <= 0x7fffffff && !lvq_tune().gemm_ln_tiles &&
         (!post_add || m <= post_rows || (post_rows % 16 == 0 && m % post_rows == 0))) {
         int rc = LVQ_EUNSUPPORTED;
         switch (n) {

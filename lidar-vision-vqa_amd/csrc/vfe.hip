@@ -445,7 +445,7 @@ extern "C" int lvq_pillar_vfe(const float *voxels, const int32_t *num_pts, const
     if (lds > 160 * 1024) return LVQ_EUNSUPPORTED;
     dim3 grid((unsigned)lvq_cdiv(m_cap, 4)), block(256);
     if (n_layers == 1 && c == 4 && t <= 32 && P.cin[0] <= 12 && P.cout[0] <= 64 && !(((uintptr_t)voxels) & 15) &&
-        getenv("LVQ_PILLAR_VFE_GENERIC") == nullptr) {
+        !lvq_tune().pillar_vfe_generic) {
         hipLaunchKernelGGL(k_pillar_vfe1, grid, block, 0, lvq_s(stream), reinterpret_cast<const float4 *>(voxels), num_pts, coords_bzyx,
                            m_cap, n_voxels_dev, t, P, out);
         return lvq_launch_status();

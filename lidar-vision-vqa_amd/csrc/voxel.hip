@@ -601,12 +601,12 @@ extern "C" int lvq_voxelize_hard(const float *pts, const int32_t *scene_off, int
     if (!ws || ws_bytes < lvq_voxelize_hard_workspace_bytes(n_points, n_scenes)) return LVQ_EWORKSPACE;
     // default: hash-balanced slabs (voxel_hashed.hip); shapes it does not take go to the slab-binned path, then to the
     // global-hash kernels below.  LVQ_VOXEL_BINNED / LVQ_VOXEL_LEGACY force the older paths (tests, A/B timing).
-    if (!break_on_cap && getenv("LVQ_VOXEL_LEGACY") == nullptr && getenv("LVQ_VOXEL_BINNED") == nullptr) {
+    if (!break_on_cap && lvq_tune().voxel_path == 0) {
         const int rc = lvq_hashed_voxelize_hard(pts, scene_off, n_points, n_scenes, c, range_host, vsize_host, grid_host, max_pts,
                                                 max_voxels, voxels, coords_bzyx, num_pts, scene_voxel_off, ws, ws_bytes, st);
         if (rc != LVQ_EUNSUPPORTED) return rc;
     }
-    if (!break_on_cap && getenv("LVQ_VOXEL_LEGACY") == nullptr) {
+    if (!break_on_cap && lvq_tune().voxel_path != 2) {
         const int rc = lvq_binned_voxelize_hard(pts, scene_off, n_points, n_scenes, c, range_host, vsize_host, grid_host, max_pts,
                                                 max_voxels, voxels, coords_bzyx, num_pts, scene_voxel_off, ws, ws_bytes, st);
         if (rc != LVQ_EUNSUPPORTED) return rc;
@@ -711,7 +711,7 @@ extern "C" int lvq_voxelize_dynamic(const float *pts, int64_t n, int c, int batc
     // (bitmap 4.5 us, scan 2.3, look-back 6.8, inverse map 15, keys / counts / coords 13 per workgroup at one 64-KiB-bitmap workgroup
     // per CU, 2.5 rounds), and smaller slabs give the time back to the binning pass (one global atomic per block and slab: 30 us at
     // 1280 slabs).  The four-kernel form keeps 4 slab workgroups per CU in flight.
-    if (getenv("LVQ_VOXEL_LEGACY") == nullptr) {       // slab-binned path first; the two-level-bitmap kernels below are the fallback
+    if (lvq_tune().voxel_path != 2) {       // slab-binned path first; the two-level-bitmap kernels below are the fallback
         const int rc = lvq_binned_voxelize_dynamic(pts, n, c, batch_size, range_host, vsize_host, grid_host, ndim, unq_inv, pt_coords,
                                                    unq_key, unq_cnt, coords_bzyx, counts, ws, ws_bytes, st);
         if (rc != LVQ_EUNSUPPORTED) return rc;

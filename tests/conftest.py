@@ -52,3 +52,18 @@ def _build_oracle():
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     yield
+
+
+@pytest.fixture
+def tune():
+    """Explicit kernel-family choices for one test (include/lvq.h: lvq_tuning through _ffi.set_tuning): `tune(attn_nsplit=1)` changes
+    fields of the record in force; the record implied by the environment is restored afterwards."""
+    from lidar_vision_vqa_amd import _ffi
+
+    def apply(**fields):
+        cur = _ffi.get_tuning()
+        cur.update(fields)
+        _ffi._push(cur)
+
+    yield apply
+    _ffi.set_tuning()

@@ -37,6 +37,37 @@ def test_host_only_entry_points(lib):
     assert lib.lvq_voxelize_dynamic_workspace_bytes(ctypes.c_int64(10), ctypes.c_int(64), g2, ctypes.c_int(3)) == 0
 
 
+def test_tuning_record_is_the_only_routing_input(lib, monkeypatch):
+    """Kernel-family choices enter through lvq_set_tuning (include/lvq.h: lvq_tuning), not through the environment: the library does not
+    import getenv at all, the record round-trips through the ABI, and the Python mirror maps the LVQ_* variables onto it."""
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--undefined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    assert ctypes.sizeof(_ffi.Tuning) == 16 * 4 + 8 + 8 * 4
+    t = _ffi.Tuning()
+    t.attn_nsplit = 7
+    lib.lvq_tuning_defaults(ctypes.byref(t))
+    assert t.attn_nsplit == 0
+    try:
+        rec = _ffi.set_tuning(attn_nsplit=3, voxel_path=2, ca_fused_stamps=1 << 40)
+        got = _ffi.get_tuning()
+        assert got == rec and got["attn_nsplit"] == 3 and got["voxel_path"] == 2 and got["ca_fused_stamps"] == 1 << 40
+        with _ffi.tuning(attn_pipe=-1):
+            assert _ffi.get_tuning()["attn_pipe"] == -1 and _ffi.get_tuning()["attn_nsplit"] == 3
+        assert _ffi.get_tuning()["attn_pipe"] == 0
+        assert lib.lvq_set_tuning(None) == 0 and not any(_ffi.get_tuning().values())
+        with pytest.raises(_ffi.LvqError):
+            _ffi.set_tuning(no_such_field=1)
+        monkeypatch.setenv("LVQ_VOXEL_BINNED", "1")
+        monkeypatch.setenv("LVQ_ATTN_NO_PIPE", "1")
+        monkeypatch.setenv("LVQ_GEMM_STREAM_C_MB", "64")
+        rec = _ffi.set_tuning()
+        assert rec["voxel_path"] == 1 and rec["attn_pipe"] == -1 and rec["gemm_stream_c_mb"] == 64 and _ffi.get_tuning() == rec
+    finally:
+        monkeypatch.undo()
+        _ffi.set_tuning()
+
+
 def test_no_cpu_fallback():
     """The product path fails loudly on CPU tensors instead of silently computing elsewhere."""
     from lidar_vision_vqa_amd import fusion, lidar

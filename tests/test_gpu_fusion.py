@@ -211,11 +211,11 @@ def test_attention(B, H, Hkv, nq, nkv, dh, use_bias, causal, split):
     assert err < (2e-2 if not split else 2e-4), err
 
 
-def test_attention_long_stream_unsplit(monkeypatch):
+def test_attention_long_stream_unsplit(tune):
     """k_attn32's direct-output path (one KV split: taken in production when batch x heads x query tiles >= 4096)."""
-    monkeypatch.setenv("LVQ_ATTN_NSPLIT", "1")
+    tune(attn_nsplit=1)
     test_attention(2, 2, 1, 120, 4096, 64, False, False, False)
-    monkeypatch.setenv("LVQ_ATTN_NSPLIT", "3")
+    tune(attn_nsplit=3)
     test_attention(1, 2, 2, 576, 8192, 64, False, False, False)
 
 

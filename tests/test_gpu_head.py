@@ -200,7 +200,7 @@ def test_decode_attention_one_query(dh, nkv, H, Hk, split):
 
 @pytest.mark.parametrize("m,n,k", [(1, 896, 896), (2, 1152, 128), (3, 100, 64), (5, 4864, 896), (8, 9728, 256), (7, 65, 4864)])
 @pytest.mark.parametrize("split", [False, True])
-def test_skinny_gemv_matches_tile_gemm(m, n, k, split, monkeypatch):
+def test_skinny_gemv_matches_tile_gemm(m, n, k, split, tune):
     """lvq_gemm_bf16 with M <= 8 (k_gemv: one pass over W, fp32 FMAs) against the MFMA tile kernels on the same operands: every
     epilogue option (bias, GELU, alpha, residual, row table; fp32 and bf16 / lo outputs), narrow and wide N (1 or 4 rows per wave),
     N not a multiple of the rows per wave."""
@@ -227,9 +227,9 @@ def test_skinny_gemv_matches_tile_gemm(m, n, k, split, monkeypatch):
 
     for gelu, alpha, use_res, use_tab in [(False, 1.0, False, False), (True, 0.5, True, True), (False, 2.0, True, False)]:
         got32, got16 = run(gelu, alpha, use_res, use_tab)
-        monkeypatch.setenv("LVQ_GEMM_NO_GEMV", "1")
+        tune(gemm_no_gemv=1)
         ref32, ref16 = run(gelu, alpha, use_res, use_tab)
-        monkeypatch.delenv("LVQ_GEMM_NO_GEMV")
+        tune(gemm_no_gemv=0)
         scale = float(ref32.abs().max()) + 1e-6
         assert (got32 - ref32).abs().max().item() < 2e-5 * scale * max(1.0, k / 256)        # same products, different summation order
         assert (got16 - ref16).abs().max().item() < (2e-5 if split else 8e-3) * scale

@@ -69,14 +69,13 @@ HARD_CASES = [
 
 
 # default = hash-balanced slabs (voxel_hashed.hip); the two older implementations stay reachable and are held to the same oracle
-VOXEL_PATHS = {"hashed": None, "binned": "LVQ_VOXEL_BINNED", "legacy": "LVQ_VOXEL_LEGACY"}
+VOXEL_PATHS = {"hashed": 0, "binned": 1, "legacy": 2}           # include/lvq.h: lvq_tuning.voxel_path
 
 
 @pytest.mark.parametrize("path", list(VOXEL_PATHS))
 @pytest.mark.parametrize("dist,n,seed,vs,T,mv,brk", HARD_CASES)
-def test_hard_voxelizer_vs_oracle(dist, n, seed, vs, T, mv, brk, path, monkeypatch):
-    if VOXEL_PATHS[path]:
-        monkeypatch.setenv(VOXEL_PATHS[path], "1")
+def test_hard_voxelizer_vs_oracle(dist, n, seed, vs, T, mv, brk, path, tune):
+    tune(voxel_path=VOXEL_PATHS[path])
     pts = masked(dist, n, seed)
     ov, oc, on = LO.VoxelGenerator(vs, RNG, 4, T, mv, break_on_cap=brk).generate(pts)
     gv, gc, gn = L().VoxelGeneratorWrapper(vs, RNG, 4, T, mv, break_on_cap=brk).generate(pts)
@@ -179,7 +178,7 @@ def test_voxelize_mean_is_bit_identical_to_voxelize_plus_mean_vfe(vs, T, mv):
     assert np.allclose(feats[:m].cpu().numpy(), np.concatenate(exp), rtol=1e-6, atol=1e-6)
 
 
-def test_hard_voxelizer_paths_agree_at_scale(monkeypatch):
+def test_hard_voxelizer_paths_agree_at_scale(tune):
     """BASELINE cfg-4 size x 16 scenes (1.92 M points in one call, max_voxels 160 000): the hash-balanced-slab path and the
     slab-binned path -- two independent implementations -- agree bit for bit on every output."""
     lid = L()
@@ -189,7 +188,7 @@ def test_hard_voxelizer_paths_agree_at_scale(monkeypatch):
     gen = lid.VoxelGeneratorWrapper(synth.VOXEL_01, RNG, 4, 10, 160000)
     a = gen.generate_batch_device(pts, off, 16)
     torch.cuda.synchronize()
-    monkeypatch.setenv("LVQ_VOXEL_BINNED", "1")
+    tune(voxel_path=1)
     b = gen.generate_batch_device(pts, off, 16)
     torch.cuda.synchronize()
     m = int(a[3][-1])
@@ -368,7 +367,7 @@ def test_full_size_properties_cfg3():
 
 @pytest.mark.parametrize("with_distance,abs_xyz,filters,T", [(False, True, [64], 20), (True, True, [64], 20), (False, False, [32], 12),
                                                              (True, False, [64], 32), (True, True, [48], 7)])
-def test_pillar_vfe_fast_kernel_flag_combinations(with_distance, abs_xyz, filters, T, monkeypatch):
+def test_pillar_vfe_fast_kernel_flag_combinations(with_distance, abs_xyz, filters, T, tune):
     """The single-layer fast kernel (k_pillar_vfe1) against the CPU restatement and against the generic kernel for every
     feature layout (WITH_DISTANCE / USE_ABSLOTE_XYZ), odd T and channel counts below 64."""
     lid = L()
@@ -380,7 +379,7 @@ def test_pillar_vfe_fast_kernel_flag_combinations(with_distance, abs_xyz, filter
                                  point_cloud_range=RNG, grid_size=[512, 512, 1]).to(DEV).eval()
     synth.load_seeded(m, 91)
     fast = m(dict(bd))["pillar_features"].cpu()
-    monkeypatch.setenv("LVQ_PILLAR_VFE_GENERIC", "1")
+    tune(pillar_vfe_generic=1)
     generic = m(dict(bd))["pillar_features"].cpu()
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     ref = LO.pillar_vfe(bd["voxels"].cpu().numpy(), bd["voxel_num_points"].cpu().numpy(), bd["voxel_coords"].cpu().numpy(), sd,

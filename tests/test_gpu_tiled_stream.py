@@ -218,12 +218,9 @@ def test_attention_tiled_equals_dense_on_gathered_rows(B, H, nq, n_tiles, qsplit
 
 @pytest.mark.parametrize("one_wg", [False, True])
 @pytest.mark.parametrize("B,nt,fr", [(4, 96, [0.3, 0.0, 0.7, 0.05]), (3, 1100, [0.27, 0.49, 0.002])])
-def test_scene_pairs_vs_numpy(B, nt, fr, one_wg, monkeypatch):
+def test_scene_pairs_vs_numpy(B, nt, fr, one_wg, tune):
     """Pair lists from the chunked two-kernel form (many workgroups per scene, the default) and from the one-workgroup-per-scene form."""
-    if one_wg:
-        monkeypatch.setenv("LVQ_PAIRS_ONE_WG", "1")
-    else:
-        monkeypatch.delenv("LVQ_PAIRS_ONE_WG", raising=False)
+    tune(pairs_one_wg=int(one_wg))
     o = ops()
     hw = nt * 64
     _, src, _ = _row_case(B, 2, nt, fr, 3)
@@ -310,9 +307,9 @@ def test_attention_tiled_signed_falls_back_when_unusable(kind):
 
 @pytest.mark.parametrize("B,H,nq,n_tiles,fr,qsplit", [(2, 2, 120, 64, 0.35, True), (3, 4, 576, 128, [0.4, 0.9, 0.0], True), (2, 12, 576, 256, [0.2, 0.45], True),
                                                       (1, 2, 120, 67, 0.3, True), (2, 2, 240, 72, 0.3, False)])
-def test_pipelined_stream_is_bit_identical(B, H, nq, n_tiles, fr, qsplit, monkeypatch):
+def test_pipelined_stream_is_bit_identical(B, H, nq, n_tiles, fr, qsplit, tune):
     """The software-pipelined form of the long-stream kernel (4 LDS slots, loader-only waves for the query padding; the default for
-    split and fp16 queries, LVQ_ATTN_PIPE=1 forces it for plain ones) against the plain form (LVQ_ATTN_NO_PIPE=1).  Same arithmetic in
+    split and fp16 queries, lvq_tuning.attn_pipe = 1 forces it for plain ones) against the plain form (attn_pipe = -1).  Same arithmetic in
     the same order: with the KV split pinned, the tiled stream, the per-model totals and the signed pair stream (pair lists of any
     length, full-list batches, 1 .. n tiles per split) are equal bit for bit."""
     o = ops()
@@ -322,13 +319,12 @@ def test_pipelined_stream_is_bit_identical(B, H, nq, n_tiles, fr, qsplit, monkey
     d = H * 64
     res = {}
     for pipe in (False, True):
-        monkeypatch.delenv("LVQ_ATTN_NO_PIPE" if pipe else "LVQ_ATTN_PIPE", raising=False)
-        monkeypatch.setenv("LVQ_ATTN_PIPE" if pipe else "LVQ_ATTN_NO_PIPE", "1")
+        tune(attn_pipe=1 if pipe else -1)
         out = {}
         for ns in ("1", "3", "8"):
             if 8 * int(ns) > n_tiles:
                 continue
-            monkeypatch.setenv("LVQ_ATTN_NSPLIT", ns)
+            tune(attn_nsplit=int(ns))
             qb = o.cast(torch.randn(nq, d, generator=torch.Generator().manual_seed(32)).to(DEV), qsplit)
             qfull = tuple(None if x is None else x.unsqueeze(0).expand(B, nq, d).reshape(B * nq, d).contiguous() for x in qb)
             out["tiled", ns] = o.attention_tiled(qfull, kv, srcd, batch=B, n_heads=H, nq=nq, n_tiles=n_tiles, dh=64, scale=0.125)
@@ -345,9 +341,7 @@ def test_pipelined_stream_is_bit_identical(B, H, nq, n_tiles, fr, qsplit, monkey
                     out["signed16", ns] = o.attention_tiled_signed(qb, kv_h, srcd, pair_src, pair_info, tot16, batch=B, n_heads=H, nq=nq, n_tiles=n_tiles,
                                                                    dh=64, scale=0.125, shared_q=True, k_fp16=True)
         res[pipe] = out
-    monkeypatch.delenv("LVQ_ATTN_NSPLIT", raising=False)
-    monkeypatch.delenv("LVQ_ATTN_PIPE", raising=False)
-    monkeypatch.delenv("LVQ_ATTN_NO_PIPE", raising=False)
+    tune(attn_nsplit=0, attn_pipe=0)
     assert res[False].keys() == res[True].keys() and len(res[True]) > 0
     for k in res[False]:
         for a, b in zip(res[False][k], res[True][k]):

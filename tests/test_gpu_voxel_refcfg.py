@@ -51,11 +51,9 @@ def voxelnext_scene(n, seed, boundary=0):
 
 @pytest.mark.parametrize("path", ["hashed", "binned", "legacy"])
 @pytest.mark.parametrize("n,mv", [(34000, 120000), (120000, 160000), (300000, 120000)])
-def test_hard_voxelnext_config_vs_oracle(n, mv, path, monkeypatch):
+def test_hard_voxelnext_config_vs_oracle(n, mv, path, tune):
     """Single scene, every implementation, bit for bit (n = 300 000 > 120 000 occupied cells: the max_voxels cap is hit)."""
-    env = {"binned": "LVQ_VOXEL_BINNED", "legacy": "LVQ_VOXEL_LEGACY"}.get(path)
-    if env:
-        monkeypatch.setenv(env, "1")
+    tune(voxel_path={"hashed": 0, "binned": 1, "legacy": 2}[path])
     pts = voxelnext_scene(n, 4000 + n, boundary=2000)
     assert L().grid_size_from(RNG_VN, VS_VN).tolist() == [1440, 1440, 40]
     ov, oc, on = LO.VoxelGenerator(VS_VN, RNG_VN, 4, 10, mv).generate(pts)
@@ -201,10 +199,8 @@ def _call_hard(scenes, vs, rng, T, mv, mean, ws_delta=0, path_env=None):
 @pytest.mark.parametrize("path", ["hashed", "binned", "legacy"])
 @pytest.mark.parametrize("case", list(GUARD_CASES))
 @pytest.mark.parametrize("vs,T,mv", [(synth.VOXEL_01, 10, 60000), (synth.VOXEL_PILLAR, 20, 30000)])
-def test_hard_voxelizer_guard_bands(case, vs, T, mv, path, monkeypatch):
-    env = {"binned": "LVQ_VOXEL_BINNED", "legacy": "LVQ_VOXEL_LEGACY"}.get(path)
-    if env:
-        monkeypatch.setenv(env, "1")
+def test_hard_voxelizer_guard_bands(case, vs, T, mv, path, tune):
+    tune(voxel_path={"hashed": 0, "binned": 1, "legacy": 2}[path])
     scenes = GUARD_CASES[case]()
     rc, bufs, cap = _call_hard(scenes, vs, RNG_NUSC, T, mv, mean=False)
     assert rc == 0, F.lib().lvq_strerror(rc)
@@ -242,11 +238,9 @@ def test_hard_voxelizer_workspace_one_byte_short_is_refused(mean):
 @pytest.mark.parametrize("path", ["binned", "legacy"])
 @pytest.mark.parametrize("case", list(GUARD_CASES))
 @pytest.mark.parametrize("ndim,vs", [(3, synth.VOXEL_01), (2, synth.VOXEL_PILLAR)])
-def test_dynamic_voxelizer_guard_bands(case, ndim, vs, path, monkeypatch):
+def test_dynamic_voxelizer_guard_bands(case, ndim, vs, path, tune):
     legacy = path
-    env = {"binned": "LVQ_VOXEL_BINNED", "legacy": "LVQ_VOXEL_LEGACY"}.get(path)
-    if env:
-        monkeypatch.setenv(env, "1")
+    tune(voxel_path={"hashed": 0, "binned": 1, "legacy": 2}[path])
     lib = F.lib()
     scenes = [s for s in GUARD_CASES[case]()]
     bs = len(scenes)

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""A/B of the long-stream attention kernel: the plain form (LVQ_ATTN_NO_PIPE=1) against the software-pipelined one (LVQ_ATTN_PIPE=1), same inputs,
+"""A/B of the long-stream attention kernel: the plain form (lvq_tuning.attn_pipe = -1) against the software-pipelined one (attn_pipe = 1), same inputs,
 outputs compared bit for bit, both timed.  Shapes as in the bench (B scenes x 12 heads x 576 queries x 4096 tiles), q hi + lo."""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from lidar_vision_vqa_amd import ops
+from lidar_vision_vqa_amd import _ffi, ops
 DEV = torch.device("cuda:0"); torch.set_grad_enabled(False)
 B = int(os.environ.get("SCENES", "8")); H, nq, nt, dh = 12, 576, 4096, 64
 d = H * dh; hw = nt * 64
@@ -19,14 +19,12 @@ def ab(name, fn, flops):
     """Outputs with the KV split pinned (same partial sums in both forms -> bit-identical), times with each form's own plan."""
     res = {}
     for mode in ("0", "1"):
-        os.environ.pop("LVQ_ATTN_PIPE", None); os.environ.pop("LVQ_ATTN_NO_PIPE", None)
-        os.environ["LVQ_ATTN_PIPE" if mode == "1" else "LVQ_ATTN_NO_PIPE"] = "1"
-        os.environ["LVQ_ATTN_NSPLIT"] = "8"
-        out = fn(); torch.cuda.synchronize()
-        outs = [o.clone() for o in out if o is not None] if isinstance(out, (tuple, list)) else [out.clone()]
-        os.environ.pop("LVQ_ATTN_NSPLIT")
-        res[mode] = (outs, timeit(fn))
-    os.environ.pop("LVQ_ATTN_PIPE", None); os.environ.pop("LVQ_ATTN_NO_PIPE", None)
+        pipe = 1 if mode == "1" else -1                    # include/lvq.h: lvq_tuning.attn_pipe
+        with _ffi.tuning(attn_pipe=pipe, attn_nsplit=8):
+            out = fn(); torch.cuda.synchronize()
+            outs = [o.clone() for o in out if o is not None] if isinstance(out, (tuple, list)) else [out.clone()]
+        with _ffi.tuning(attn_pipe=pipe):
+            res[mode] = (outs, timeit(fn))
     same = all(torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b)
                for a, b in zip(res["0"][0], res["1"][0]))
     dmax = max(float((a.float() - b.float()).abs().max()) for a, b in zip(res["0"][0], res["1"][0]))

@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-from lidar_vision_vqa_amd import fusion, synth
+from lidar_vision_vqa_amd import _ffi, fusion, synth
 dev = torch.device("cuda:0")
 torch.set_grad_enabled(False)
 B, nq, nkv = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (1, 32768, 196)
@@ -17,10 +17,9 @@ for _ in range(int(os.environ.get('WARM', '3'))):
     blk.cross_attention(q, kv)
 nwg = B * ((nq + 127) // 128)
 st = torch.zeros(nwg * 4 * 8, dtype=torch.int64, device=dev)
-os.environ["LVQ_CA_STAMPS"] = str(st.data_ptr())
-blk.cross_attention(q, kv)
-torch.cuda.synchronize()
-del os.environ["LVQ_CA_STAMPS"]
+with _ffi.tuning(ca_fused_stamps=st.data_ptr()):          # include/lvq.h: lvq_tuning.ca_fused_stamps
+    blk.cross_attention(q, kv)
+    torch.cuda.synchronize()
 raw = st.cpu().numpy().reshape(nwg, 4, 8)
 t = raw[:, :, :6].astype(np.float64) / 100.0   # us
 cyc = (raw[:, :, 7] - raw[:, :, 6]).astype(np.float64)
