@@ -369,16 +369,17 @@ def main():
     flops_h = 4.0 * 32768 * d * d + 4.0 * 196 * d * d + 4.0 * 32768 * 196 * d          # SURVEY 8d F_ca: 97.5 GFLOP
     fused_route = "ca_fused" in ev_h
     if fused_route:
-        ms_h = avg_ms(ev_h["ca_fused"])
+        ms_single = avg_ms(ev_h["ca_fused"])                    # one event pair per call: includes the event packets and an empty queue's launch gap
+        ms_h = float(np.mean([event_ms(lambda: blk.cross_attention(qh, kvh), iters=20, warm=0) for _ in range(3)]))   # 20 calls back to back per event pair
         # executed MFMA FLOPs: the 196 keys run as 7 blocks of 32 (224 key slots) in both attention products and in the K|V projection
         flops_ex = 4.0 * 32768 * d * d + 4.0 * 224 * d * d + 4.0 * 32768 * 224 * d
         tr, src = profile_traffic([f"lvq_ca_fused 1x32768x196 {prec}"])
         kern = ("lvq_ca_fused = k_ca_kvproj + k_ca_fused (csrc/cross_fused.hip): LayerNorm, Q projection, softmax(Q K^T) V, out projection, bias and fp32 "
                 "residual of `q + ca(ca_ln(q), kv, kv)` in one kernel, " + ("IEEE fp16" if prec != "bf16" else "bf16") + " MFMA operands (32x32x16), fp32 accumulation; "
-                "HIP events around the two launches on the launch stream, 20 launches")
+                "HIP events on the launch stream around 20 back-to-back calls (2 launches each), mean of 3 batches; `single_call_event_ms` = one event pair per call")
     else:                                                       # bf16x3: the unfused hi + lo chain (5 launches)
         ms_h = event_ms(lambda: blk.cross_attention(qh, kvh), iters=10)
-        flops_ex, tr, src = flops_h * 3.0, None, None
+        flops_ex, tr, src, ms_single = flops_h * 3.0, None, None, None
         kern = "unfused chain (LayerNorm, Q / K|V / out projections, attention): hi + lo operands, three MFMA passes; whole sub-path"
     ach = flops_h / (ms_h * 1e-3) / 1e12
     result["roofline"] = {
@@ -386,7 +387,7 @@ def main():
         "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
         "frac_algorithmic": round(ach / PEAK_BF16_TFLOPS, 4), "frac_executed": round(flops_ex / (ms_h * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         "flops_per_launch": flops_h, "flops_executed": flops_ex, "avg_launch_ms": round(ms_h, 4),
-        "algorithmic_bytes": 2.0 * 32768 * d * 4 + 196 * d * 4 + 4.0 * d * d * 2, "traffic": tr, "traffic_source": src,
+        "single_call_event_ms": None if ms_single is None else round(ms_single, 4), "algorithmic_bytes": 2.0 * 32768 * d * 4 + 196 * d * 4 + 4.0 * d * d * 2, "traffic": tr, "traffic_source": src,
         "hbm_floor_ms": round((2.0 * 32768 * d * 4) / (PEAK_HBM_GBS * 1e9) * 1e3, 4), "mfma_floor_ms": round(flops_h / (PEAK_BF16_TFLOPS * 1e12) * 1e3, 4)}
     del qh, kvh
 
