@@ -14,7 +14,7 @@ from typing import List, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblvq_hip.so")
+LIB_PATH = os.environ.get("LVQ_LIB_PATH") or os.path.join(_HERE, "liblvq_hip.so")     # LVQ_LIB_PATH: another build of the same ABI (A/B runs)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lvq.h")
 
 LVQ_OK = 0

@@ -1240,13 +1240,14 @@ __global__ void __launch_bounds__(256) k_attn_combine_signed(AttnArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int dq = a.dh / 4;
     const int64_t total = (int64_t)a.B * a.H * a.Nq * dq;
-    if (idx >= total) return;
-    const int d0 = (int)(idx % dq) * 4;
-    const int64_t row = idx / dq;                    // (b*H + h)*Nq + qi
+    const int64_t idc = idx < total ? idx : total - 1;         // every lane stays to the wave reduction below; lanes past the end compute a copy, store nothing
+    const int d0 = (int)(idc % dq) * 4;
+    const int64_t row = idc / dq;                    // (b*H + h)*Nq + qi
     const int qi = (int)(row % a.Nq);
     const int64_t bh = row / a.Nq;
     const int h = (int)(bh % a.H), b = (int)(bh / a.H);
-    if (a.pred && a.pred[bh] == 0) return;
+    const bool live = idx < total && !(a.pred && a.pred[bh] == 0);
+    if (!live && !a.stats) return;                              // (the predicated re-run's merge carries no statistics: unflagged rows leave at once)
     const int stride = a.dh + 2;
     const bool signed_b = !a.pred && a.pair_info && a.pair_info[2 * b + 1] != 0;
     const float *tot = signed_b ? a.totals + ((int64_t)h * a.Nq + qi) * stride : nullptr;
@@ -1268,16 +1269,30 @@ __global__ void __launch_bounds__(256) k_attn_combine_signed(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] += w * pr[d0 + r];
     }
-    if (signed_b && d0 == 0 && a.flags && !(l > 0.0625f * lt && l < 3.0e38f)) {
+    const bool judge = live && signed_b && d0 == 0;
+    if (judge && a.flags && !(l > 0.0625f * lt && l < 3.0e38f)) {
         a.flags[bh] = 1;
         if (a.stats && qi == 0) atomicAdd(&a.stats[1], 1);
     }
-    // per-launch half of the plain-stream guard (lvq_stream_guard is the per-model half): this row's softmax mass sits mostly on the
-    // scene's own (dirty) keys, which the per-model statistic has not seen
-    if (signed_b && d0 == 0 && a.stats && lt > 0.f) {
-        if (l > 1.5f * lt) atomicAdd(&a.stats[0], 1);
-        atomicMax(reinterpret_cast<unsigned int *>(&a.stats[2]), __float_as_uint(fminf(l / lt, 3.0e38f)));      // positive floats order like their bits
+    // per-launch half of the plain-stream guard (lvq_stream_guard is the per-model half): rows whose softmax mass sits mostly on the
+    // scene's own (dirty) keys, which the per-model statistic has not seen -> a count and the largest l / l_table.  Reduced over the
+    // wave first and sent only when it can change the result: one same-address atomic per row serialised 221 000 of them (0.8 ms).
+    if (a.stats) {                                              // (wave-uniform: a kernel argument)
+        float ratio = (judge && lt > 0.f) ? fminf(l / lt, 3.0e38f) : 0.f;
+        int over = (judge && lt > 0.f && l > 1.5f * lt) ? 1 : 0;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            ratio = fmaxf(ratio, __shfl_xor(ratio, o));
+            over += __shfl_xor(over, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (over) atomicAdd(&a.stats[0], over);
+            const unsigned int bits = __float_as_uint(ratio);   // non-negative floats order like their bits
+            if (bits > __hip_atomic_load(reinterpret_cast<unsigned int *>(&a.stats[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(reinterpret_cast<unsigned int *>(&a.stats[2]), bits);
+        }
     }
+    if (!live) return;
     const float inv = l > 0.f ? 1.0f / l : 0.f;
     float y[4];
 #pragma unroll

@@ -39,6 +39,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
+#ifndef CA_EARLY_READS
+#define CA_EARLY_READS 0
+#endif
 constexpr int D = 768, NH = 12, DH = 64;
 constexpr int NKS = D / 16;                 // 48 k-steps of a 768-deep product
 constexpr int FRAG = 1024;                  // bytes of one fragment = one wave-instruction of 16 B per lane
@@ -344,7 +347,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
         auto mid = [&](auto mi) __attribute__((always_inline)) {
             constexpr int m = decltype(mi)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (m == 0 && !LATE && !(DBG & 4)) {                        // all four right behind the first MFMA: three MFMAs of cover
+            if constexpr (m == 0 && !LATE && !(DBG & 4) && !CA_EARLY_READS) {     // all four right behind the first MFMA: three MFMAs of cover
                 lds_read<nbase>(nxt[0], fr_addr);
                 lds_read<nbase + FRAG>(nxt[1], fr_addr);
                 lds_read<nbase + 2 * FRAG>(nxt[2], fr_addr);
@@ -364,6 +367,13 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         };
+        if constexpr (!LATE && CA_EARLY_READS) {                                  // experiment: ahead of the first MFMA (four MFMAs of cover)
+            lds_read<nbase>(nxt[0], fr_addr);
+            lds_read<nbase + FRAG>(nxt[1], fr_addr);
+            lds_read<nbase + 2 * FRAG>(nxt[2], fr_addr);
+            lds_read<nbase + 3 * FRAG>(nxt[3], fr_addr);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         body(cur, mid);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LATE) {
@@ -394,32 +404,57 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
     // head h + 1's first batches: accumulators are double-buffered by head parity.  Four units (dh-block blk, half sx); unit u reads
     // its four table vectors at the end of batch 2 u and computes in batch 2 u + 1 (the batch-start wait has retired the reads).
     f32x16 qacc[2][2];                                           // [head parity][dh-block]
-    f32x4 tq4[4];                                                // table vectors of the unit in flight: bias' (2), row sums (2)
+    f32x4 tq4[2][4];                                             // table vectors of two units (set = unit parity): bias' (2), row sums (2)
     h16x8 qfr[4];
     auto q_unit_read = [&](auto hi, auto ui) __attribute__((always_inline)) {
         constexpr int h = decltype(hi)::value, blk = decltype(ui)::value >> 1, sx = decltype(ui)::value & 1;
         if constexpr (DBG & 16) return;
-        lds_read<(64 * h + 32 * blk + 16 * sx) * 4>(tq4[0], tb_addr);
-        lds_read<(64 * h + 32 * blk + 16 * sx + 8) * 4>(tq4[1], tb_addr);
-        lds_read<(D + 64 * h + 32 * blk + 16 * sx) * 4>(tq4[2], tb_addr);
-        lds_read<(D + 64 * h + 32 * blk + 16 * sx + 8) * 4>(tq4[3], tb_addr);
+        constexpr int set = decltype(ui)::value & 1;
+        lds_read<(64 * h + 32 * blk + 16 * sx) * 4>(tq4[set][0], tb_addr);
+        lds_read<(64 * h + 32 * blk + 16 * sx + 8) * 4>(tq4[set][1], tb_addr);
+        lds_read<(D + 64 * h + 32 * blk + 16 * sx) * 4>(tq4[set][2], tb_addr);
+        lds_read<(D + 64 * h + 32 * blk + 16 * sx + 8) * 4>(tq4[set][3], tb_addr);
     };
     // quarter qq of unit u: two of its eight values per call... (row = dh of register r of block blk: 32 blk + (r & 3) + 8 (r >> 2) + 4 h2)
     uint32_t qw[4];
     auto q_unit_quarter = [&](auto hi, auto ui, auto qi) __attribute__((always_inline)) {
         constexpr int h = decltype(hi)::value, u = decltype(ui)::value, blk = u >> 1, sx = u & 1, qq = decltype(qi)::value;
         if constexpr (DBG & 16) return;
-        if constexpr (qq == 0) asm volatile("" : "+v"(tq4[0]), "+v"(tq4[1]), "+v"(tq4[2]), "+v"(tq4[3]));      // behind the batch-start wait (asm order)
+        constexpr int set = u & 1;
+        if constexpr (qq == 0) asm volatile("" : "+v"(tq4[set][0]), "+v"(tq4[set][1]), "+v"(tq4[set][2]), "+v"(tq4[set][3]));      // behind the batch-start wait (asm order)
         const f32x16 &acc = qacc[h & 1][blk];
         float e0, e1;
         {
             constexpr int j = 2 * qq;
-            e0 = __builtin_fmaf(acc[8 * sx + j], q_a, __builtin_fmaf(-tq4[2 + (j >> 2)][j & 3], q_b, tq4[j >> 2][j & 3]));
-            e1 = __builtin_fmaf(acc[8 * sx + j + 1], q_a, __builtin_fmaf(-tq4[2 + ((j + 1) >> 2)][(j + 1) & 3], q_b, tq4[(j + 1) >> 2][(j + 1) & 3]));
+            e0 = __builtin_fmaf(acc[8 * sx + j], q_a, __builtin_fmaf(-tq4[set][2 + (j >> 2)][j & 3], q_b, tq4[set][j >> 2][j & 3]));
+            e1 = __builtin_fmaf(acc[8 * sx + j + 1], q_a, __builtin_fmaf(-tq4[set][2 + ((j + 1) >> 2)][(j + 1) & 3], q_b, tq4[set][(j + 1) >> 2][(j + 1) & 3]));
         }
         if (F16) e0 = clamp16(e0), e1 = clamp16(e1);
         qw[qq] = pack2<F16>(e0, e1);
         if constexpr (qq == 3) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 w4 = {qw[0], qw[1], qw[2], qw[3]};
+            h16x8 fr = __builtin_bit_cast(h16x8, w4);
+            pin(fr);
+            if constexpr (h < QL) lds_write<(4 * h + u) * FRAG>(rs_addr, fr);
+            else {
+                qf[4 * h + u] = fr;
+                pin(qf[4 * h + u]);
+            }
+        }
+    };
+    // one value (v = 0 .. 7) of unit u: the thin slice (<= 5 vector instructions) that hides in one MFMA gap
+    float qe = 0.f;
+    auto q_unit_value = [&](auto hi, auto ui, auto vi) __attribute__((always_inline)) {
+        constexpr int h = decltype(hi)::value, u = decltype(ui)::value, blk = u >> 1, sx = u & 1, v = decltype(vi)::value, set = u & 1;
+        if constexpr (DBG & 16) return;
+        if constexpr (v == 0) asm volatile("" : "+v"(tq4[set][0]), "+v"(tq4[set][1]), "+v"(tq4[set][2]), "+v"(tq4[set][3]));      // behind a batch-start wait (asm order)
+        const f32x16 &acc = qacc[h & 1][blk];
+        float e = __builtin_fmaf(acc[8 * sx + v], q_a, __builtin_fmaf(-tq4[set][2 + (v >> 2)][v & 3], q_b, tq4[set][v >> 2][v & 3]));
+        if (F16) e = clamp16(e);
+        if constexpr (v % 2 == 0) qe = e;
+        else qw[v >> 1] = pack2<F16>(qe, e);
+        if constexpr (v == 7) {
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             u32x4 w4 = {qw[0], qw[1], qw[2], qw[3]};
             h16x8 fr = __builtin_bit_cast(h16x8, w4);
@@ -440,10 +475,16 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
                 // epilogue slices of the previous head: batches 0, 2, 4, 6 end with a unit's table reads, batches 1, 3, 5, 7 compute it
                 auto vs = [&](auto si) __attribute__((always_inline)) {
                     constexpr int sl = decltype(si)::value;
-                    if constexpr (h > 0 && lb < 8) {
-                        constexpr int u = lb / 2;
-                        if constexpr (lb % 2 == 1) q_unit_quarter(std::integral_constant<int, (h > 0 ? h - 1 : 0)>{}, std::integral_constant<int, u>{}, si);
-                        else if constexpr (sl == 3) q_unit_read(std::integral_constant<int, (h > 0 ? h - 1 : 0)>{}, std::integral_constant<int, u>{});
+                    // gap g = 4 lb + sl of this head: value g - 4 - 8 u of unit u of the previous head in gaps 4 + 8 u .. 11 + 8 u (batches 1 .. 8);
+                    // unit u's table vectors are requested a whole batch or more ahead, into the register set its parity names: gaps 0, 4, 12, 20
+                    if constexpr (h > 0 && lb < 9) {
+                        constexpr int g = 4 * lb + sl;
+                        using HP = std::integral_constant<int, (h > 0 ? h - 1 : 0)>;
+                        if constexpr (g == 0) q_unit_read(HP{}, std::integral_constant<int, 0>{});
+                        if constexpr (g == 4) q_unit_read(HP{}, std::integral_constant<int, 1>{});
+                        if constexpr (g == 12) q_unit_read(HP{}, std::integral_constant<int, 2>{});
+                        if constexpr (g == 20) q_unit_read(HP{}, std::integral_constant<int, 3>{});
+                        if constexpr (g >= 4) q_unit_value(HP{}, std::integral_constant<int, (g >= 4 ? (g - 4) / 8 : 0)>{}, std::integral_constant<int, (g >= 4 ? (g - 4) % 8 : 0)>{});
                     }
                 };
                 if constexpr (lb == 0) qacc[par][0] = mfma_d(f[0], xd[ks], zero);
@@ -467,7 +508,7 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
     // the last head's epilogue has no projection left to hide under (the next batch's fragment reads are in flight: requested by the last step)
     static_for<0, 4>([&](auto ui) {
         q_unit_read(std::integral_constant<int, NH - 1>{}, ui);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tq4[0]), "+v"(tq4[1]), "+v"(tq4[2]), "+v"(tq4[3])::"memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(tq4[decltype(ui)::value & 1][0]), "+v"(tq4[decltype(ui)::value & 1][1]), "+v"(tq4[decltype(ui)::value & 1][2]), "+v"(tq4[decltype(ui)::value & 1][3])::"memory");
         static_for<0, 4>([&](auto qi) { q_unit_quarter(std::integral_constant<int, NH - 1>{}, ui, qi); });
         __builtin_amdgcn_sched_barrier(0);
     });
