@@ -11,12 +11,12 @@ Drop-in for (citations relative to /root/reference/src/):
 Same constructor signatures, same `state_dict()` keys and shapes (SURVEY.md Appendix D -- torch's
 nn.LayerNorm / nn.Linear / nn.MultiheadAttention / nn.Conv2d objects are kept as PARAMETER CONTAINERS so
 checkpoints load unchanged and default initialisation consumes the RNG exactly like the reference),
-same forward signatures, fp32 in / fp32 out.  The forward pass never calls those containers: all
-arithmetic runs in liblvq_hip.so (bf16 MFMA, fp32 statistics/accumulation).
+same forward signatures, fp32 in / fp32 out.  The inference forward (eval() under torch.no_grad(), the reference's hot path) never
+calls those containers: all arithmetic runs in liblvq_hip.so (bf16 MFMA, fp32 statistics/accumulation), and there is no fallback for it.
 
-Inference only: forward under torch.is_grad_enabled() with trainable inputs/params raises (the
-reference's autograd/training path is not part of this round's scope); dropout is the identity,
-as in the reference's eval() mode.
+The kernels are forward-only.  A call in train() mode, or in grad mode with a trainable parameter or input, takes the autograd route
+instead (autograd_route.py: the containers as ordinary torch modules; SURVEY 8b: "must fall back to torch ops when
+torch.is_grad_enabled()"), so the reference's trainer can differentiate through the same objects; it warns once per class.
 """
 from __future__ import annotations
 
@@ -28,6 +28,7 @@ import torch
 import torch.nn as nn
 
 from . import _ffi as F
+from . import autograd_route as AG
 from . import ops
 from .ops import BF
 
@@ -71,13 +72,17 @@ class _HipModule(nn.Module):
         return bf
 
     def _guard(self, *tensors):
-        if self.training:
-            raise F.LvqError(f"{type(self).__name__}: the MI355X path is inference-only; call .eval() "
-                             "(dropout is the identity there, as in the reference)")
-        if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors if t is not None)
-                                        or any(p.requires_grad for p in self.parameters())):
-            raise F.LvqError(f"{type(self).__name__}: autograd is not implemented on the HIP path; wrap the call in torch.no_grad()")
+        """The HIP route: eval() under no_grad() on CUDA tensors, or a loud error (callers ask _autograd() first)."""
+        if AG.wanted(self, *tensors):
+            raise F.LvqError(f"{type(self).__name__}: this entry point has no autograd route; call it in eval() mode under torch.no_grad()")
         F.require_cuda(*[t for t in tensors if t is not None])
+
+    def _autograd(self, *tensors) -> bool:
+        """True when this call belongs to the autograd route (train() mode or gradients needed): torch ops, see autograd_route.py."""
+        if AG.wanted(self, *tensors):
+            AG.note(self)
+            return True
+        return False
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -234,6 +239,8 @@ class VATBlock(_HipModule):
         return self._mlp(q2)
 
     def forward(self, q: torch.Tensor, kv: torch.Tensor) -> torch.Tensor:
+        if self._autograd(q, kv):
+            return AG.vat_block(self, q, kv)
         self._guard(q, kv)
         B, nq, d = q.shape
         nkv = kv.shape[1]
@@ -682,6 +689,8 @@ class VATLiDAR(_HipModule):
             self.precision = keep
 
     def forward(self, bev: torch.Tensor) -> torch.Tensor:
+        if self._autograd(bev):
+            return AG.vat_lidar(self, bev)
         self._guard(bev)
         B, C, H, W = bev.shape
         x = self.bev_tokens(bev)
@@ -740,10 +749,12 @@ class VATVision(_HipModule):
                                   nn.Linear(d_model, d_model), nn.LayerNorm(d_model))
 
     def forward(self, kv_tokens: torch.Tensor) -> torch.Tensor:
-        self._guard(kv_tokens)
         B, N, D = kv_tokens.shape
         assert N == self.n_input_tokens, f"Expected {self.n_input_tokens} input tokens, got {N}"
         assert D == self.d_in, f"Expected d_in={self.d_in}, got {D}"
+        if self._autograd(kv_tokens):
+            return AG.vat_vision(self, kv_tokens)
+        self._guard(kv_tokens)
         split = self._split()
         kv = ops.cast(_f32(kv_tokens).view(B * N, D), split)
         q0 = self.query.detach().float().contiguous()
@@ -784,6 +795,8 @@ class VisionAdapter(_HipModule):
                 hw = t.shape[0]
             elif t.shape[0] != hw:
                 raise ValueError(f"All views must have same HW. Got {hw} and {t.shape[0]}.")
+        if self._autograd(*views_tokens):
+            return AG.vision_adapter(self, views_tokens)
         self._guard(*views_tokens)
         x = torch.cat([_f32(t) for t in views_tokens], dim=0)            # view-major rows: group v = rows v*hw..(v+1)*hw
         out, _ = ops.layernorm(x, self.norm.weight, self.norm.bias, self.norm.eps, False, want_f32=True, want_bf=False,
@@ -825,6 +838,8 @@ class MlpProjectorLinear(_HipModule):
         self.layers = nn.Linear(input_dim, n_embed)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self._autograd(x):
+            return self.layers(x)
         self._guard(x)
         shp = x.shape
         y, _ = ops.linear(ops.cast(_f32(x).view(-1, shp[-1]), self._split()), self._w(self.layers.weight), self.layers.bias,

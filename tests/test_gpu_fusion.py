@@ -300,7 +300,8 @@ def test_vat_block_golden(name, prec):
 
 
 def test_vat_block_api_surface():
-    """state_dict keys == the reference's; train mode / autograd are refused loudly."""
+    """state_dict keys == the reference's; train mode / grad mode take the autograd route (torch ops), which
+    agrees with the kernels; the inference route has no CPU fallback."""
     f = fusion()
     m = f.VATBlock(96, 4, 384, 0.1)
     keys = set(m.state_dict().keys())
@@ -310,13 +311,22 @@ def test_vat_block_api_surface():
     expect |= {"mlp_ln.weight", "mlp_ln.bias", "mlp.0.weight", "mlp.0.bias", "mlp.3.weight", "mlp.3.bias"}
     assert keys == expect
     m = m.to(DEV)
-    q, kv = torch.zeros(1, 6, 96, device=DEV), torch.zeros(1, 5, 96, device=DEV)
-    with pytest.raises(Exception):
-        m.train()(q, kv)
-    with pytest.raises(Exception):
-        m.eval()(q, kv)                      # grad enabled + trainable params
+    synth.load_seeded(m, 77)
+    q, kv = dev(synth.randn((1, 6, 96), 78)), dev(synth.randn((1, 5, 96), 79))
+    with pytest.warns(UserWarning, match="autograd route"):
+        y = m.eval()(q, kv)                  # grad enabled + trainable params -> torch ops with a graph
+    assert y.requires_grad and y.grad_fn is not None
+    y.sum().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    with torch.no_grad():
+        z = m.eval()(q, kv)                  # the kernels
+    assert not z.requires_grad and (z - y.detach()).abs().max().item() < 1e-3
+    t = m.train()(q, kv)                     # dropout active: stochastic, finite, differentiable
+    assert t.requires_grad and bool(torch.isfinite(t).all())
     with pytest.raises(Exception), torch.no_grad():
-        m.eval()(q.cpu(), kv.cpu())          # no CPU fallback
+        m.eval()(q.cpu(), kv.cpu())          # no CPU fallback of the inference route
+    with pytest.raises(Exception):
+        m.eval().cross_attention(q, kv)      # kernel-only entry point: no autograd route
 
 
 @pytest.mark.parametrize("name", list(cases.VAT_LIDAR_CASES))
