@@ -49,6 +49,7 @@ struct AttnArgs {
     int32_t *flags;           // out, per (b, h): the signed result of some query is unusable (non-finite, or cancellation too deep)
     const int32_t *pred;      // in, per (b, h): workgroups / rows of (b, h) with pred == 0 do nothing (the predicated full re-run)
     int force_part;           // write partials even when nsplit == 1
+    int32_t *stat_slots;      // [STAT_SLOTS][64] scratch of the guard statistics (per slot: count | max ratio bits), zeroed per call; with pred set: reduced into stats
     int32_t *stats;           // optional [4] (accumulated): rows whose own (dirty) keys dominate the softmax mass | (batch, head) pairs re-run | max l / l_table (float bits) | -
 };
 
@@ -1236,18 +1237,42 @@ __global__ void __launch_bounds__(256) k_attn_combine(AttnArgs a) {
 // normalise -- and JUDGE the result: a signed sum is only as good as what is left after the subtraction.  With T the total row sum
 // over all table keys and l the final one, fp32 accumulation error is ~2^-20 T, so l < T / 16 (or a non-finite / non-positive l)
 // flags (b, h) for the predicated full re-run.  With pred set this is that re-run's merge (rows of unflagged (b, h) are left alone).
+constexpr int STAT_SLOTS = 256;        // same-address atomics serialise (and device-scope loads of one address do too: every XCD's L2 is bypassed)
 __global__ void __launch_bounds__(256) k_attn_combine_signed(AttnArgs a) {
+    __shared__ int s_over[4];
+    __shared__ unsigned int s_bits[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (a.pred && a.stats && a.stat_slots && blockIdx.x == 0) {
+        // the re-run's merge doubles as the last step of the guard statistics: the first launch left one (count, max) pair per slot
+        int over = a.stat_slots[threadIdx.x * 64];
+        unsigned int bits = (unsigned int)a.stat_slots[threadIdx.x * 64 + 1];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            over += __shfl_xor(over, o);
+            const unsigned int t = (unsigned int)__shfl_xor((int)bits, o);
+            bits = bits > t ? bits : t;
+        }
+        if (lane == 0) { s_over[wid] = over; s_bits[wid] = bits; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            over = s_over[0] + s_over[1] + s_over[2] + s_over[3];
+            bits = max(max(s_bits[0], s_bits[1]), max(s_bits[2], s_bits[3]));
+            if (over) atomicAdd(&a.stats[0], over);
+            if (bits) atomicMax(reinterpret_cast<unsigned int *>(&a.stats[2]), bits);
+        }
+    }
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int dq = a.dh / 4;
     const int64_t total = (int64_t)a.B * a.H * a.Nq * dq;
-    const int64_t idc = idx < total ? idx : total - 1;         // every lane stays to the wave reduction below; lanes past the end compute a copy, store nothing
+    const bool slots = !a.pred && a.stat_slots != nullptr;       // (uniform) every lane stays to the block reduction below; lanes past the end compute a copy, store nothing
+    const int64_t idc = idx < total ? idx : total - 1;
     const int d0 = (int)(idc % dq) * 4;
     const int64_t row = idc / dq;                    // (b*H + h)*Nq + qi
     const int qi = (int)(row % a.Nq);
     const int64_t bh = row / a.Nq;
     const int h = (int)(bh % a.H), b = (int)(bh / a.H);
     const bool live = idx < total && !(a.pred && a.pred[bh] == 0);
-    if (!live && !a.stats) return;                              // (the predicated re-run's merge carries no statistics: unflagged rows leave at once)
+    if (!live && !slots) return;                                // (the predicated re-run's merge: rows of unflagged (b, h) leave at once)
     const int stride = a.dh + 2;
     const bool signed_b = !a.pred && a.pair_info && a.pair_info[2 * b + 1] != 0;
     const float *tot = signed_b ? a.totals + ((int64_t)h * a.Nq + qi) * stride : nullptr;
@@ -1275,9 +1300,10 @@ __global__ void __launch_bounds__(256) k_attn_combine_signed(AttnArgs a) {
         if (a.stats && qi == 0) atomicAdd(&a.stats[1], 1);
     }
     // per-launch half of the plain-stream guard (lvq_stream_guard is the per-model half): rows whose softmax mass sits mostly on the
-    // scene's own (dirty) keys, which the per-model statistic has not seen -> a count and the largest l / l_table.  Reduced over the
-    // wave first and sent only when it can change the result: one same-address atomic per row serialised 221 000 of them (0.8 ms).
-    if (a.stats) {                                              // (wave-uniform: a kernel argument)
+    // scene's own (dirty) keys, which the per-model statistic has not seen -> a count and the largest l / l_table.  One atomic per row on
+    // one address serialised 221 000 of them (0.8 ms); reading the address first was worse (1.2 ms).  So: reduce over the workgroup, one
+    // atomic pair per workgroup into one of STAT_SLOTS lines, and the re-run's merge (above) folds the slots into stats.
+    if (slots) {
         float ratio = (judge && lt > 0.f) ? fminf(l / lt, 3.0e38f) : 0.f;
         int over = (judge && lt > 0.f && l > 1.5f * lt) ? 1 : 0;
 #pragma unroll
@@ -1285,11 +1311,14 @@ __global__ void __launch_bounds__(256) k_attn_combine_signed(AttnArgs a) {
             ratio = fmaxf(ratio, __shfl_xor(ratio, o));
             over += __shfl_xor(over, o);
         }
-        if ((threadIdx.x & 63) == 0) {
-            if (over) atomicAdd(&a.stats[0], over);
-            const unsigned int bits = __float_as_uint(ratio);   // non-negative floats order like their bits
-            if (bits > __hip_atomic_load(reinterpret_cast<unsigned int *>(&a.stats[2]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMax(reinterpret_cast<unsigned int *>(&a.stats[2]), bits);
+        if (lane == 0) { s_over[wid] = over; s_bits[wid] = __float_as_uint(ratio); }      // non-negative floats order like their bits
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            over = s_over[0] + s_over[1] + s_over[2] + s_over[3];
+            const unsigned int bits = max(max(s_bits[0], s_bits[1]), max(s_bits[2], s_bits[3]));
+            int32_t *slot = a.stat_slots + (blockIdx.x & (STAT_SLOTS - 1)) * 64;
+            if (over) atomicAdd(&slot[0], over);
+            if (bits) atomicMax(reinterpret_cast<unsigned int *>(&slot[1]), bits);
         }
     }
     if (!live) return;
@@ -1722,7 +1751,8 @@ extern "C" size_t lvq_attention_tiled_signed_workspace_bytes(int batch, int n_he
     if (nkv > 0x7fffffff) return 0;
     const AttnPlan pl = plan_k32_any(batch, n_heads, nq, (int)nkv, dh);
     if (!pl.k32) return 0;
-    return (size_t)batch * n_heads * pl.nsplit * nq * (dh + 2) * sizeof(float) + (size_t)batch * n_heads * sizeof(int32_t) + 512;
+    return (size_t)batch * n_heads * pl.nsplit * nq * (dh + 2) * sizeof(float) + (size_t)batch * n_heads * sizeof(int32_t) +
+           (size_t)STAT_SLOTS * 64 * sizeof(int32_t) + 768;
 }
 
 // As lvq_attention_bf16_tiled, with the per-batch pair lists of lvq_bev_scene_pairs and the per-model totals.  The queries must be the
@@ -1761,6 +1791,7 @@ extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16
     LvqArena arena(ws, ws_bytes);
     a.part = arena.take<float>((size_t)batch * n_heads * pl.nsplit * nq * (dh + 2));
     int32_t *flags = arena.take<int32_t>((size_t)batch * n_heads);
+    int32_t *stat_slots = stats ? arena.take<int32_t>((size_t)STAT_SLOTS * 64) : nullptr;
     if (!arena.ok) return LVQ_EWORKSPACE;
     hipStream_t st = lvq_s(stream);
     const size_t lds = K32_LDS_TILED;
@@ -1769,12 +1800,14 @@ extern "C" int lvq_attention_bf16_tiled_signed(const lvq_bf16 *q, const lvq_bf16
     if (nwg > 0x7fffffff) return LVQ_EUNSUPPORTED;
     const int64_t total = (int64_t)a.B * a.H * a.Nq * (a.dh / 4);
     if (hipMemsetAsync(flags, 0, (size_t)batch * n_heads * sizeof(int32_t), st) != hipSuccess) return LVQ_ELAUNCH;
+    if (stat_slots && hipMemsetAsync(stat_slots, 0, (size_t)STAT_SLOTS * 64 * sizeof(int32_t), st) != hipSuccess) return LVQ_ELAUNCH;
     a.flags = flags;
     a.stats = stats;
+    a.stat_slots = stat_slots;
     launch_k32<2>(a, pl.k32, qs, nwg, lds, st);
     hipLaunchKernelGGL(k_attn_combine_signed, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
     // predicated full re-run of the flagged (batch, head) pairs: every workgroup of an unflagged pair returns at once
-    a.flags = nullptr; a.stats = nullptr; a.pred = flags; a.pair_src = nullptr; a.pair_info = nullptr; a.totals = nullptr;
+    a.flags = nullptr; a.pred = flags; a.pair_src = nullptr; a.pair_info = nullptr; a.totals = nullptr;      // (stats / stat_slots stay: folded by this merge)
     launch_k32<1>(a, pl.k32, qs, nwg, lds, st);
     hipLaunchKernelGGL(k_attn_combine_signed, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, a);
     return lvq_launch_status();
