@@ -357,29 +357,39 @@ __global__ void __launch_bounds__(DYN_NT) k_dyn_slab_write(BinCfg cfg, Geom g, c
         else atomicAdd(&unq_cnt[vbase + lr], 1);          // oversized slab: counters in global memory (pre-zeroed)
     }
     __syncthreads();
-    // unique outputs in ascending key order: sequential stores
+    // unique outputs in ascending key order.  Voxel v of the slab belongs to thread v % DYN_NT: consecutive lanes write consecutive rows
+    // (full-line stores) and every thread gets the same number of voxels.  (Round 2 walked the bitmap instead, four words per thread:
+    // the occupied cells of a LiDAR slab are clustered, so a few threads held up to 256 voxels -- each with three reciprocal divisions --
+    // while most held none, and the slab's time was that serial tail: 45 of the path's 82 us.)
     const int64_t key0 = (int64_t)s << cfg.logslab;
     const float rx = 1.0f / (float)g.grid[0], ry = 1.0f / (float)g.grid[1], rz = 1.0f / (float)g.grid[2];
-    for (int j = 0; j < per; ++j) {
-        const int w = threadIdx.x * per + j;
-        if (w >= nw) break;
-        unsigned long long bits = bm[w];
-        int lr = wpre[w];
-        while (bits) {
-            const int bit = __builtin_ctzll(bits);
-            bits &= bits - 1;
-            const int key = (int)(key0 + w * 64 + bit);
-            const int v = vbase + lr;
-            unq_key[v] = key;
-            if (lds_cnt) unq_cnt[v] = cnt_l[lr];
-            // key -> (b, cx, cy, cz) with float-reciprocal division (exact for key < 2^30 after the fix-up step)
-            int b, cx, cy, cz = 0, t = key;
-            if (cfg.ndim == 3) { const int q = fdiv(t, g.grid[2], rz); cz = t - q * g.grid[2]; t = q; }
-            { const int q = fdiv(t, g.grid[1], ry); cy = t - q * g.grid[1]; t = q; }
-            { const int q = fdiv(t, g.grid[0], rx); cx = t - q * g.grid[0]; b = q; }
-            reinterpret_cast<int4 *>(coords_bzyx)[v] = make_int4(b, cz, cy, cx);
-            ++lr;
+    for (int v = threadIdx.x; v < nvox; v += DYN_NT) {
+        // the word that holds the v-th occupied cell: the LAST w with wpre[w] <= v (wpre = exclusive popcount prefix; empty words repeat it)
+        int lo = 0, hi = nw - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (wpre[mid] <= v) lo = mid; else hi = mid - 1;
         }
+        const unsigned long long bits = bm[lo];
+        int k = v - wpre[lo];                                      // its k-th set bit (0-based), by halving
+        unsigned int x = (unsigned int)bits;
+        int pos = 0, c = __popc(x);
+        if (k >= c) { k -= c; x = (unsigned int)(bits >> 32); pos = 32; }
+        c = __popc(x & 0xffffu); if (k >= c) { k -= c; x >>= 16; pos += 16; } x &= 0xffffu;
+        c = __popc(x & 0xffu);   if (k >= c) { k -= c; x >>= 8;  pos += 8; }  x &= 0xffu;
+        c = __popc(x & 0xfu);    if (k >= c) { k -= c; x >>= 4;  pos += 4; }  x &= 0xfu;
+        c = __popc(x & 0x3u);    if (k >= c) { k -= c; x >>= 2;  pos += 2; }  x &= 0x3u;
+        if (k >= (int)(x & 1u)) pos += 1;
+        const int key = (int)(key0 + lo * 64 + pos);
+        const int vo = vbase + v;
+        unq_key[vo] = key;
+        if (lds_cnt) unq_cnt[vo] = cnt_l[v];
+        // key -> (b, cx, cy, cz) with float-reciprocal division (exact for key < 2^30 after the fix-up step)
+        int bq, cx, cy, cz = 0, t = key;
+        if (cfg.ndim == 3) { const int q = fdiv(t, g.grid[2], rz); cz = t - q * g.grid[2]; t = q; }
+        { const int q = fdiv(t, g.grid[1], ry); cy = t - q * g.grid[1]; t = q; }
+        { const int q = fdiv(t, g.grid[0], rx); cx = t - q * g.grid[0]; bq = q; }
+        reinterpret_cast<int4 *>(coords_bzyx)[vo] = make_int4(bq, cz, cy, cx);
     }
 }
 
