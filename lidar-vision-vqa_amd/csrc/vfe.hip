@@ -209,11 +209,20 @@ __global__ void __launch_bounds__(256) k_pillar_vfe1(const float4 *__restrict__ 
     wave_sync();
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     float mx = -INFINITY;
+    // The padding slots (np .. T - 1) carry all-zero feature rows (pillar_vfe.py:117-120), so each of them yields the same value per channel:
+    // the accumulator stays +0 and y = (+0) * scale + shift.  It is taken once, with the same two operations, instead of T - np times --
+    // a LiDAR pillar holds 3-4 points on average against T = 20 or 32 slots (the loop below was 3 rounds of 8 slots for every pillar).
+    const int jmax = np < T ? np : T;                        // (wave-uniform: one pillar per wave)
+    if (jmax < T) {
+        const float zero = 0.f;
+        const float ypad = zero * sc + sh;
+        mx = fmaxf(ypad, 0.f);
+    }
     // per point: acc = sum_k f[k] * w[k] in ascending k from 0 (the order of the scalar form: bit-identical), then BN + ReLU + max
     auto quads = [&](auto kk_tag) __attribute__((always_inline)) {
         constexpr int KK = decltype(kk_tag)::value;
         const f32x2 sc2 = {sc, sc}, sh2 = {sh, sh};
-        for (int j0 = 0; j0 < T; j0 += 8) {                   // two quads per round: four independent accumulation chains
+        for (int j0 = 0; j0 < jmax; j0 += 8) {                // two quads per round: four independent accumulation chains
             f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
             for (int k = 0; k < KK; ++k) {
@@ -228,8 +237,8 @@ __global__ void __launch_bounds__(256) k_pillar_vfe1(const float4 *__restrict__ 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x2 y = acc[q] * sc2 + sh2;               // (mul, then add: -ffp-contract=off, as the scalar form)
-                if (j0 + 2 * q < T) mx = fmaxf(mx, fmaxf(y[0], 0.f));
-                if (j0 + 2 * q + 1 < T) mx = fmaxf(mx, fmaxf(y[1], 0.f));
+                if (j0 + 2 * q < jmax) mx = fmaxf(mx, fmaxf(y[0], 0.f));
+                if (j0 + 2 * q + 1 < jmax) mx = fmaxf(mx, fmaxf(y[1], 0.f));
             }
         }
     };
