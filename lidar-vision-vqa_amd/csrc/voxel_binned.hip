@@ -393,15 +393,16 @@ __global__ void __launch_bounds__(DYN_NT) k_dyn_slab_write(BinCfg cfg, Geom g, c
     }
 }
 
-// slab size: average ~256-512 points per slab, dense bitmap <= 16 KB (logslab <= 17), at most MAX_SLABS slabs
-static bool choose_cfg(int64_t keyspace, int64_t n, BinCfg &cfg) {
-    if (keyspace <= 0 || keyspace > (1ll << 30)) return false;
+// slab size: average ~256-512 points per slab, dense bitmap <= 16 KB (logslab <= 17), at most MAX_SLABS slabs.  max_ls = 18 (dynamic path:
+// 32-KB bitmaps, key spaces up to 2^31 -- e.g. 32 scenes of the 0.1 m nuScenes grid -- instead of handing those to the bitmap kernels of voxel.hip)
+static bool choose_cfg(int64_t keyspace, int64_t n, BinCfg &cfg, int max_ls = 17) {
+    if (keyspace <= 0 || keyspace > ((int64_t)MAX_SLABS << max_ls) || keyspace >= (1ll << 31)) return false;
     int64_t want = n / 384 + 1;
     if (want > MAX_SLABS) want = MAX_SLABS;
     int ls = 10;
-    while (ls < 17 && ((keyspace + (1ll << ls) - 1) >> ls) > want) ++ls;
+    while (ls < 17 && ((keyspace + (1ll << ls) - 1) >> ls) > want) ++ls;      // (the preferred size stays <= 17)
     while (((keyspace + (1ll << ls) - 1) >> ls) > MAX_SLABS) {
-        if (ls >= 17) return false;
+        if (ls >= max_ls) return false;
         ++ls;
     }
     cfg.logslab = ls;
@@ -693,7 +694,7 @@ int lvq_binned_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_si
     int64_t keyspace = (int64_t)batch_size * grid_host[0] * grid_host[1];
     if (ndim == 3) keyspace *= grid_host[2];
     BinCfg cfg;
-    if (!choose_cfg(keyspace, n, cfg)) return LVQ_EUNSUPPORTED;
+    if (!choose_cfg(keyspace, n, cfg, 18)) return LVQ_EUNSUPPORTED;
     cfg.ndim = ndim; cfg.n_scenes = batch_size; cfg.mode = 0;
     LvqArena arena(ws, ws_bytes);
     DynBinWs w;
@@ -713,6 +714,8 @@ int lvq_binned_voxelize_dynamic(const float *pts, int64_t n, int c, int batch_si
     hipLaunchKernelGGL(k_dyn_slab_count, dim3(cfg.nslabs), dim3(DYN_NT), sizeof(unsigned long long) * nw, st, cfg, w.gstart, w.soff,
                        w.slab_cnt);
     const size_t lds = sizeof(unsigned long long) * nw + sizeof(int32_t) * nw + sizeof(int32_t) * DYN_VCAP;
+    static LvqLdsOnce once_dyn;
+    if (lds > 48 * 1024 && !lvq_ensure_lds(once_dyn, {(const void *)k_dyn_slab_write}, 80 * 1024)) return LVQ_ELAUNCH;
     hipLaunchKernelGGL(k_dyn_slab_write, dim3(cfg.nslabs), dim3(DYN_NT), lds, st, cfg, g, w.gstart, w.sidx, w.soff, w.slab_cnt, unq_inv,
                        unq_key, unq_cnt, coords_bzyx, &counts[0]);
     return lvq_launch_status();
