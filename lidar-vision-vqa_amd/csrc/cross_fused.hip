@@ -39,9 +39,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 
-#ifndef CA_EARLY_READS
-#define CA_EARLY_READS 0
-#endif
 constexpr int D = 768, NH = 12, DH = 64;
 constexpr int NKS = D / 16;                 // 48 k-steps of a 768-deep product
 constexpr int FRAG = 1024;                  // bytes of one fragment = one wave-instruction of 16 B per lane
@@ -347,7 +344,8 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
         auto mid = [&](auto mi) __attribute__((always_inline)) {
             constexpr int m = decltype(mi)::value;
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (m == 0 && !LATE && !(DBG & 4) && !CA_EARLY_READS) {     // all four right behind the first MFMA: three MFMAs of cover
+            if constexpr (m == 0 && !LATE && !(DBG & 4)) {                        // all four right behind the first MFMA: three MFMAs of cover
+                // (ahead of the first MFMA -- four MFMAs of cover -- measured 6 % slower in phase A: the wait at the batch start is not what costs)
                 lds_read<nbase>(nxt[0], fr_addr);
                 lds_read<nbase + FRAG>(nxt[1], fr_addr);
                 lds_read<nbase + 2 * FRAG>(nxt[2], fr_addr);
@@ -367,13 +365,6 @@ __global__ void __launch_bounds__(NW * 64, 1) k_ca_fused(CaArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        if constexpr (!LATE && CA_EARLY_READS) {                                  // experiment: ahead of the first MFMA (four MFMAs of cover)
-            lds_read<nbase>(nxt[0], fr_addr);
-            lds_read<nbase + FRAG>(nxt[1], fr_addr);
-            lds_read<nbase + 2 * FRAG>(nxt[2], fr_addr);
-            lds_read<nbase + 3 * FRAG>(nxt[3], fr_addr);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         body(cur, mid);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (LATE) {
