@@ -474,6 +474,25 @@ def main():
             del p4, b4
         except Exception as err:                                # never let a secondary figure cost the line
             result["value_n_layers_4"] = {"error": str(err)[:200]}
+        # ---- the reference's own dataflow: PointPillarScatter materialises the dense canvas, VATLiDAR.forward(bev) consumes it (round 3: the occupied
+        #      cells come back out of the canvas -- lvq_bev_occupied_cells -- and the sparse key stream runs; LVQ_NO_DENSE_SPARSE=1: the dense route) ----
+        try:
+            sd_ = min(S, 8)
+            pd = P.FusionPipeline(cfg, dev, precision=prec, dense_bev=True)
+            bd = P.synthetic_batch(cfg, sd_, 1100, dev)
+            msd = event_ms(lambda: pd(*bd[:3]), iters=3, warm=2)
+            os.environ["LVQ_NO_DENSE_SPARSE"] = "1"
+            try:
+                msd0 = event_ms(lambda: pd(*bd[:3]), iters=2, warm=1)
+            finally:
+                del os.environ["LVQ_NO_DENSE_SPARSE"]
+            result["value_dense_canvas_input"] = {"value": round(sd_ * cfg.n_queries / msd * 1e3, 1), "ms_per_step": round(msd, 3), "scenes_per_step": sd_,
+                                                  "dense_route_value": round(sd_ * cfg.n_queries / msd0 * 1e3, 1), "dense_route_ms_per_step": round(msd0, 3),
+                                                  "note": "same workload through the reference's call VATLiDAR.forward(bev) on a materialised [S, 64, 512, 512] canvas "
+                                                          "(vat_lidar.py:187; canvas write + occupied-cell extraction included); `value` feeds the pillars directly"}
+            del pd, bd
+        except Exception as err:
+            result["value_dense_canvas_input"] = {"error": str(err)[:200]}
         # ---- every cross-attention row of SURVEY 8d, all modes; the first row is the literal headline shape ----
         ca = cross_attention_rows(P, fusion, dev)
         result["cross_attention_rows"] = ca

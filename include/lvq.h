@@ -388,6 +388,14 @@ int lvq_ca_fused_pack(const float *ln_gamma, const float *ln_beta, const float *
 int lvq_ca_fused(const float *q, const float *kv, const void *packed, float eps, int batch, int nq, int nkv, int d, int n_heads, int f16,
                  float *out, void *ws, size_t ws_bytes, lvq_stream_t stream);
 
+/* The inverse of lvq_pillar_scatter: the occupied cells of a dense BEV canvas [batch, c, h, w] (fp32) as pillars -- feats [cap, c], coords (b, 0, y, x)
+ * [cap, 4], *n_cells = their number (zeroed by the call; may exceed cap: rows past cap are not written).  A cell whose c channels are all zero is exactly an
+ * absent pillar for VATLiDAR's refine conv, so VATLiDAR.forward(bev) -- the reference's own entry point (vat_lidar.py:187-304; the fp16 .npy canvases of
+ * precompute_bev_features.py:391-395 are mostly empty) -- can take the sparse key stream of lvq_bev_tile_kv.  Row order follows the allocation atomics
+ * (not reproducible); everything downstream addresses pillars through coordinates.  The reference has no counterpart: it always runs the dense canvas. */
+int lvq_bev_occupied_cells(const float *bev, int batch, int c, int h, int w, int64_t cap, float *feats, int32_t *coords_bzyx, int32_t *n_cells,
+                           lvq_stream_t stream);
+
 /* VATLiDAR front (vat_lidar.py:82-85,212): depthwise Conv2d(C,C,3,pad=1,groups=C) + exact GELU on
  * NCHW fp32 input, written TOKEN-MAJOR [B, H*W, C] as bf16 (the A operand of the 1x1-conv GEMM). */
 int lvq_dwconv3x3_gelu(const float *bev, const float *w9, const float *bias, int batch, int ch, int h, int w,

@@ -347,3 +347,78 @@ extern "C" int lvq_sparse_to_dense(const float *feats, const int32_t *indices, i
     hipLaunchKernelGGL(k_dense_lines, dim3((unsigned)lines), dim3(256), sizeof(float) * (DENSE_CH * (w + 1) + w), st, feats, map, c, d, h, w, out);
     return lvq_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Dense BEV canvas -> its occupied cells (the inverse of PointPillarScatter): what lets VATLiDAR.forward(bev), the reference's own entry
+// point (vat_lidar.py:187, fed by the fp16 .npy canvases of precompute_bev_features.py:391-395), take the sparse key stream of
+// bev_tiles.hip.  A cell whose C channels are all zero is exactly an absent pillar: the refine conv sees zeros there either way.
+// One thread per cell: the C channel planes are read coalesced along x, a wave allots its occupied cells contiguous rows with ONE atomic,
+// and the rows leave through an LDS transpose ([channel][cell], pitch 65: conflict-free), two cells per step, as 128-byte row segments.  Row order
+// follows the atomics: downstream addresses pillars through the coordinate -> row map only, so results do not depend on it.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+// LDS hand-off between lanes of ONE wave (the LDS queue is in order per wave: only the compiler must be kept from reordering)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__global__ void __launch_bounds__(256) k_bev_cells(const float *__restrict__ bev, int batch, int c, int h, int w, int64_t cap,
+                                                   float *__restrict__ feats, int32_t *__restrict__ coords, int32_t *__restrict__ n_cells) {
+    __shared__ float stage[4][32][65];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int64_t hw = (int64_t)h * w, total = (int64_t)batch * hw;
+    const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool in = cell < total;
+    const int64_t cc = in ? cell : total - 1;
+    const int b = (int)(cc / hw);
+    const int64_t yx = cc - (int64_t)b * hw;
+    const float *src = bev + (int64_t)b * c * hw + yx;
+    bool nz = false;
+    for (int k0 = 0; k0 < c; k0 += 8) {                          // eight independent loads in flight
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (k0 + u < c) ? src[(int64_t)(k0 + u) * hw] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) nz = nz || (v[u] != 0.f);
+    }
+    nz = nz && in;
+    const unsigned long long mask = __ballot(nz);
+    if (mask == 0ull) return;                                    // (wave-uniform)
+    const int cnt = __popcll(mask);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(n_cells, cnt);
+    base = __shfl(base, 0);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    const int64_t row = (int64_t)base + rank;
+    if (nz && row < cap) reinterpret_cast<int4 *>(coords)[row] = make_int4(b, 0, (int)(yx / w), (int)(yx % w));
+    // the wave's occupied cells in rank order (the lanes that hold them), two per step: lanes 0..31 and 32..63 write 32 channels each
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int k0 = 0; k0 < c; k0 += 32) {                         // 32 channels at a time through the transpose
+        const int kc = c - k0 < 32 ? c - k0 : 32;
+        for (int k = 0; k < kc; ++k) stage[wid][k][lane] = nz ? src[(int64_t)(k0 + k) * hw] : 0.f;       // (L2-hot: just read)
+        wave_sync();
+        unsigned long long m = mask;
+        for (int r = 0; r < cnt; r += 2) {
+            const int c0 = __builtin_ctzll(m);
+            m &= m - 1;
+            int c1 = c0;
+            if (r + 1 < cnt) { c1 = __builtin_ctzll(m); m &= m - 1; }
+            const int cl = half ? c1 : c0;
+            const int64_t ro = (int64_t)base + r + half;
+            if (l31 < kc && r + half < cnt && ro < cap) feats[ro * c + k0 + l31] = stage[wid][l31][cl];
+        }
+        wave_sync();
+    }
+}
+}  // namespace
+
+extern "C" int lvq_bev_occupied_cells(const float *bev, int batch, int c, int h, int w, int64_t cap, float *feats, int32_t *coords_bzyx,
+                                      int32_t *n_cells, lvq_stream_t stream) {
+    if (!bev || batch <= 0 || c <= 0 || h <= 0 || w <= 0 || cap < 0 || !feats || !coords_bzyx || !n_cells) return LVQ_EINVAL;
+    const int64_t total = (int64_t)batch * h * w;
+    if (total >= (1ll << 31) || (((uintptr_t)coords_bzyx) & 15)) return LVQ_EUNSUPPORTED;
+    hipStream_t st = lvq_s(stream);
+    if (hipMemsetAsync(n_cells, 0, sizeof(int32_t), st) != hipSuccess) return LVQ_ELAUNCH;
+    hipLaunchKernelGGL(k_bev_cells, dim3((unsigned)lvq_cdiv(total, 256)), dim3(256), 0, st, bev, batch, c, h, w, cap, feats, coords_bzyx, n_cells);
+    return lvq_launch_status();
+}

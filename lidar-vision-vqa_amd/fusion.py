@@ -377,6 +377,10 @@ class VATLiDAR(_HipModule):
                 and self._mode() in ("bf16", "mixed", "mixed16") and ops.attention_stream_ok(self.n_queries, H * W, 64)
                 and not os.environ.get("LVQ_NO_TILED_STREAM"))
 
+    def _sparse_route_ok(self, C: int, H: int, W: int) -> bool:
+        """_tiled_route_ok and whole groups of four tiles (the row granularity of the tile kernels)."""
+        return self._tiled_route_ok(C, H, W) and not (H // 8) * (W // 8) * 64 % 256
+
     def _pe_tiled(self, H: int, W: int, dev) -> torch.Tensor:
         """The positional table with its rows in the key order of the tiled stream: tile t (8 x 8 cells) major, then piece p = 2 (y >> 1)
         + (x >> 2) (2 x 4 cells), then 4 (y & 1) + (x & 3) inside the piece -- a permutation of _pe_table."""
@@ -618,7 +622,7 @@ class VATLiDAR(_HipModule):
         C = pillar_features.shape[1]
         dev = pillar_features.device
         feat = _f32(pillar_features)
-        tiled = self._tiled_route_ok(C, H, W) and not (H // 8) * (W // 8) * 64 % 256
+        tiled = self._sparse_route_ok(C, H, W)
         guarded = tiled and self._mode() in ("mixed", "mixed16") and not os.environ.get("LVQ_NO_STREAM_GUARD")
         if guarded:
             # The plain-bf16 key stream is parity-true only while the softmax mass is spread over many keys.  Two checks of the
@@ -693,6 +697,11 @@ class VATLiDAR(_HipModule):
             return AG.vat_lidar(self, bev)
         self._guard(bev)
         B, C, H, W = bev.shape
+        if self._sparse_route_ok(C, H, W) and not os.environ.get("LVQ_NO_DENSE_SPARSE"):
+            # the reference's own entry point on the sparse key stream: an all-zero cell of the canvas is exactly an absent pillar (the refine
+            # conv sees zeros there either way), and LiDAR canvases are mostly empty -- occupied cells out, then the pillar route
+            feats, coords, n_cells = ops.bev_occupied_cells(_f32(bev))
+            return self.forward_pillars(feats, coords, n_cells, B, H, W)
         x = self.bev_tokens(bev)
         return self._decode(x, B, H, W)
 

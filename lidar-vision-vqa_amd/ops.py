@@ -222,6 +222,21 @@ def attention_stream_ok(nq: int, nkv: int, dh: int) -> bool:
     return bool(F.lib().lvq_attention_stream_ok(F.cint(nq), F.cint(nkv), F.cint(dh)))
 
 
+def bev_occupied_cells(bev: torch.Tensor, cap: Optional[int] = None):
+    """Dense canvas [B, C, H, W] fp32 -> its occupied cells as pillars: feats [cap, C] fp32, coords [cap, 4] int32 (b, 0, y, x), n [1] int32 on the
+    device (rows >= n are not written; cap defaults to every cell).  lvq_bev_occupied_cells: the inverse of PointPillarScatter."""
+    F.require_cuda(bev)
+    B, C, H, W = bev.shape
+    cap = B * H * W if cap is None else int(cap)
+    feats = torch.empty((cap, C), dtype=torch.float32, device=bev.device)
+    coords = torch.empty((cap, 4), dtype=torch.int32, device=bev.device)
+    n = torch.empty(1, dtype=torch.int32, device=bev.device)
+    rc = F.lib().lvq_bev_occupied_cells(F.ptr(bev), F.cint(B), F.cint(C), F.cint(H), F.cint(W), F.i64(cap), F.ptr(feats), F.ptr(coords), F.ptr(n),
+                                        F.stream_ptr(bev.device))
+    F.check(rc, "lvq_bev_occupied_cells")
+    return feats, coords, n
+
+
 def dwconv3x3_gelu(bev: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], split: bool) -> BF:
     """bev [B,C,H,W] fp32 -> tokens BF [B*H*W, C]."""
     F.require_cuda(bev, w, b)
