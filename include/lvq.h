@@ -261,7 +261,8 @@ int lvq_pillar_index_map(const int32_t *coords_bzyx, int64_t m_cap, const int32_
  *   row_src     [batch * ny * nx]     per (scene s, key e) at s * ny * nx + e: row_base + (dirty-row number) for a dirty cell, e (its row
  *                                     in the per-model table, which occupies rows 0 .. ny*nx-1 of the same K|V buffer) otherwise
  *   counts      [3]                   live pieces, rows of the live pieces (8 x), dirty rows
- * force_all != 0 marks every cell dirty (table build with row_base = 0; dense comparator). */
+ * force_all != 0 marks every cell dirty (table build with row_base = 0; dense comparator).
+ * Reference: the key / value tokens of vat_lidar.py:222-248, which this bookkeeping lets the kernels compute for the dirty cells only. */
 size_t lvq_bev_tiles_workspace_bytes(int batch, int ny, int nx);
 int lvq_bev_tiles(const int32_t *idx_map, int batch, int ny, int nx, int force_all, int row_base, int32_t *live_list, int32_t *piece_dirty,
                   int32_t *row_src, int32_t *counts, void *ws, size_t ws_bytes, lvq_stream_t stream);
@@ -292,12 +293,12 @@ int lvq_bev_tile_kv(const float *pillar_feat, const int32_t *idx_map, const int3
                     const lvq_bf16 *m, const lvq_bf16 *m_lo, const float *m0, const lvq_bf16 *r, const lvq_bf16 *r_lo, const float *r0, float c0,
                     int d_ln, float eps, const void *t_tiled, int t_f16, int n, int k_fp16, lvq_bf16 *kv, void *ws, size_t ws_bytes,
                     lvq_stream_t stream);
-/* c[0 .. *m_rows_dev) = a @ w^T + bias over the live rows only (the row count stays on the device); m_cap, n multiples of 256,
- * k of 64.  Operand forms as lvq_gemm_bf16 (plain | a plain, w hi + lo | both hi + lo). */
+/* c[0 .. *m_rows_dev) = a @ w^T + bias over the live rows only (the row count stays on the device; vat_blocks.py:42: the K|V
+ * projection inside `ca`, restricted to the rows that differ from the per-model table); m_cap, n multiples of 256, k of 64.  Operand forms as lvq_gemm_bf16 (plain | a plain, w hi + lo | both hi + lo). */
 int lvq_gemm_bf16_live_rows(const lvq_bf16 *a, const lvq_bf16 *a_lo, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,
                             int64_t m_cap, const int32_t *m_rows_dev, int n, int k, int64_t lda, int64_t ldw, int64_t ldc,
                             lvq_bf16 *c_bf16, lvq_bf16 *c_lo, lvq_stream_t stream);
-/* softmax(q K^T * scale) V over the tiled stream: key slot r (0..63) of tile t of batch b is row row_src[(b * n_tiles + t) * 64 + r] of
+/* vat_blocks.py:41-42 for VATLiDAR's key stream (vat_lidar.py:272-285): softmax(q K^T * scale) V over the tiled stream: key slot r (0..63) of tile t of batch b is row row_src[(b * n_tiles + t) * 64 + r] of
  * k_rows / v_rows -- ONE K|V buffer holding the per-model table rows and the computed rows of every batch (lvq_bev_tiles' row_src).
  * Shapes of lvq_attention_stream_ok(nq, 64 * n_tiles, 64) only; q plain or hi + lo (mixed mode), K / V plain.
  * k_fp16 != 0 ("mixed16"): the K columns of the buffer hold IEEE fp16 (lvq_bev_tile_kv with k_fp16), q (hi + lo summed) is rounded once
@@ -353,7 +354,8 @@ size_t lvq_stream_guard_workspace_bytes(int nq, int64_t nkv);
 int lvq_stream_guard(const lvq_bf16 *q, const lvq_bf16 *k_rows, int n_heads, int nq, int64_t nkv, int64_t ldq, int64_t ldk, float scale, float *g,
                      void *ws, size_t ws_bytes, lvq_stream_t stream);
 
-/* 1 when the long-stream kernel takes (nq, nkv, dh) without bias / mask: head_dim 64, nkv >= 4096 and a multiple of 64, query
+/* nn.MultiheadAttention's scaled-dot-product core (vat_blocks.py:39,42; clip_sdpa.py:50-66; sam_vary_sdpa.py:27-42) and its shape query:
+ * 1 when the long-stream kernel takes (nq, nkv, dh) without bias / mask: head_dim 64, nkv >= 4096 and a multiple of 64, query
  * count with at most 1/8 padding to 128 / 192 rows.  Those are the shapes for which lvq_attention_bf16 accepts the "mixed" operand
  * form q = hi + lo, k / v plain (k_lo = v_lo = NULL): Q-side rounding is common to all keys of a row and does not average out
  * over the stream, K / V / P roundings do.  Any other shape with that operand form returns LVQ_EUNSUPPORTED. */
@@ -427,7 +429,8 @@ int lvq_rope_inplace(lvq_bf16 *x, lvq_bf16 *x_lo, int64_t rows, int seq_len, int
  * new positions pos0 .. pos0 + seq_len - 1 of every sequence (position = pos0 + row % seq_len). */
 int lvq_rope_inplace_at(lvq_bf16 *x, lvq_bf16 *x_lo, int64_t rows, int seq_len, int pos0, int n_heads, int dh, int64_t ld,
                         float theta, lvq_stream_t stream);
-/* greedy decoding: out_idx[r] = index of the first maximum of x[r, 0..n) (torch.argmax on finite logits). */
+/* greedy decoding (inference_engine.py:283-296 with do_sample = False): out_idx[r] = index of the first maximum of x[r, 0..n)
+ * (torch.argmax on finite logits). */
 int lvq_argmax_rows(const float *x, int64_t rows, int n, int64_t *out_idx, lvq_stream_t stream);
 /* e   payload of the per-step all-reduce (training/utils/distributed.py:7-26, commu_utils.py:148-168): out[c] = sum over rows of
  * x[r, c], fp32, in a fixed (run-to-run identical) order.  rows = 0 gives zeros. */
@@ -442,7 +445,8 @@ int lvq_colsum(const float *x, int64_t rows, int d, float *out, void *ws, size_t
 int lvq_sample_rows(const float *logits, int64_t rows, int vocab, float temperature, int top_k, float top_p, const float *u,
                     int64_t *out_idx, lvq_stream_t stream);
 int lvq_swiglu(const float *gate_up, int64_t rows, int inter, lvq_bf16 *out_hi, lvq_bf16 *out_lo, lvq_stream_t stream);
-/* sum over rows with labels[row] >= 0 of (logsumexp(logits[row]) - logits[row, label]) and their count:
+/* (trainer.py:674-675 / validation.py:105-158: `out.loss` of base(inputs_embeds, labels))
+ * sum over rows with labels[row] >= 0 of (logsumexp(logits[row]) - logits[row, label]) and their count:
  * loss = loss_sum_cnt[0] / loss_sum_cnt[1] (transformers causal-LM loss; labels already shifted by the
  * caller, -100 = ignore).  loss_sum_cnt [2] fp32 must be zero on entry. */
 int lvq_cross_entropy(const float *logits, const int64_t *labels, int64_t rows, int vocab, float *loss_sum_cnt,
@@ -492,7 +496,8 @@ int lvq_sparse_to_dense(const float *feats, const int32_t *indices, int index_co
  *   x [batch, d] fp32: embedding of the new token in, hidden state out (final norm + lm head are the caller's)
  *   layers: HOST array of n_layers structs of DEVICE pointers; weights are bf16 (hi) with optional lo parts (precision 3)
  *   caches [batch, lmax, dkv] bf16 (post-rotary keys); pos < lmax; precision: 1 = bf16, 3 = bf16x3 */
-/* RMSNorm fused into a skinny projection (m <= 8 rows): C = (RMSNorm(x) * gamma rounded to bf16[, lo]) @ W^T (+ bias); the
+/* (decode loop of inference_engine.py:283-296 -> transformers generate with a KV cache, one token per step)
+ * RMSNorm fused into a skinny projection (m <= 8 rows): C = (RMSNorm(x) * gamma rounded to bf16[, lo]) @ W^T (+ bias); the
  * rounding and summation order are lvq_rmsnorm's, so the result is bit-identical to lvq_rmsnorm + lvq_gemm_bf16. */
 int lvq_gemv_rmsnorm_bf16(const float *x, const float *gamma, float eps, const lvq_bf16 *w, const lvq_bf16 *w_lo, const float *bias,
                           int m, int n, int k, int64_t ldw, int64_t ldc, float *c_f32, lvq_bf16 *c_bf16, lvq_bf16 *c_lo,
@@ -507,6 +512,7 @@ typedef struct {
     const lvq_bf16 *wdown, *wdown_lo;             /* [d, inter] */
     lvq_bf16 *k_cache, *k_cache_lo, *v_cache, *v_cache_lo;
 } lvq_qwen2_layer;
+/* one decode step of every layer (inference_engine.py:283-296 -> transformers generate, one new token against the KV cache): contract above */
 size_t lvq_qwen2_decode_workspace_bytes(int batch, int d, int n_heads, int n_kv_heads, int inter, int lmax, int precision);
 int lvq_qwen2_decode_step(const lvq_qwen2_layer *layers, int n_layers, float *x, int batch, int d, int n_heads, int n_kv_heads,
                           int inter, int pos, int lmax, float rms_eps, float rope_theta, int precision, void *ws, size_t ws_bytes,

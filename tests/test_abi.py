@@ -25,6 +25,15 @@ def test_exports_every_declared_symbol(lib):
     assert not missing, missing
 
 
+def test_integration_md_lists_every_entry_point():
+    """INTEGRATION.md's appendix (tools/gen_abi_table.py) names every function the header declares, with the reference interface it cites."""
+    import os
+    txt = open(os.path.join(os.path.dirname(_ffi.HEADER_PATH), "..", "INTEGRATION.md")).read()
+    table = txt[txt.index("abi-table:begin"):]
+    missing = [n for n in _ffi.declared_symbols() if f"| `{n}` |" not in table]
+    assert not missing, f"run tools/gen_abi_table.py: {missing}"
+
+
 def test_host_only_entry_points(lib):
     assert b"gfx950" in lib.lvq_version()
     assert lib.lvq_strerror(0) == b"ok" and b"workspace" in lib.lvq_strerror(-2)
