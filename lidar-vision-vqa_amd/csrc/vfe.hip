@@ -164,8 +164,9 @@ __global__ void __launch_bounds__(256) k_pillar_vfe1(const float4 *__restrict__ 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int64_t m = n_live ? (int64_t)*n_live : m_cap;
     if (m > m_cap) m = m_cap;
-    const int64_t v = (int64_t)blockIdx.x * 4 + wid;
-    if (v >= m) return;                                      // whole wave exits together; no block barrier below
+    constexpr int PPW = 4;                                   // pillars per wave: the lane's weight row, scale and shift are fetched once for all of them
+    const int64_t v_first = ((int64_t)blockIdx.x * 4 + wid) * PPW;
+    if (v_first >= m) return;                                // whole wave exits together; no block barrier below
     const int cin = P.cin[0], cout = P.cout[0];
     const bool abs_xyz = P.flags & 1;
     // this lane's output channel: weight row + folded BatchNorm, requested before anything depends on them
@@ -177,6 +178,7 @@ __global__ void __launch_bounds__(256) k_pillar_vfe1(const float4 *__restrict__ 
         for (int k = 0; k < FP; ++k) wreg[k] = (k < cin) ? wrow[k] : 0.f;
     }
     const float sc = act ? P.scale[0][lane] : 0.f, sh = act ? P.shift[0][lane] : 0.f;
+    for (int64_t v = v_first; v < v_first + PPW && v < m; ++v) {
     const int np = num_pts[v];
     const int4 co = reinterpret_cast<const int4 *>(coords)[v];   // (b, z, y, x)
     float4 pt = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -245,6 +247,8 @@ __global__ void __launch_bounds__(256) k_pillar_vfe1(const float4 *__restrict__ 
     if (cin <= 10) quads(std::integral_constant<int, 10>{});
     else           quads(std::integral_constant<int, 12>{});
     if (act) out[v * cout + lane] = mx;
+    wave_sync();                                             // the next pillar's feature rows overwrite this one's
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -455,7 +459,8 @@ extern "C" int lvq_pillar_vfe(const float *voxels, const int32_t *num_pts, const
     dim3 grid((unsigned)lvq_cdiv(m_cap, 4)), block(256);
     if (n_layers == 1 && c == 4 && t <= 32 && P.cin[0] <= 12 && P.cout[0] <= 64 && !(((uintptr_t)voxels) & 15) &&
         !lvq_tune().pillar_vfe_generic) {
-        hipLaunchKernelGGL(k_pillar_vfe1, grid, block, 0, lvq_s(stream), reinterpret_cast<const float4 *>(voxels), num_pts, coords_bzyx,
+        // 4 waves x 4 pillars per workgroup
+        hipLaunchKernelGGL(k_pillar_vfe1, dim3((unsigned)lvq_cdiv(m_cap, 16)), block, 0, lvq_s(stream), reinterpret_cast<const float4 *>(voxels), num_pts, coords_bzyx,
                            m_cap, n_voxels_dev, t, P, out);
         return lvq_launch_status();
     }
