@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) k_pillar_vfe1(const float4 *__restrict__ 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int64_t m = n_live ? (int64_t)*n_live : m_cap;
     if (m > m_cap) m = m_cap;
-    constexpr int PPW = 4;                                   // pillars per wave: the lane's weight row, scale and shift are fetched once for all of them
+    constexpr int PPW = 8;                                   // pillars per wave: the lane's weight row, scale and shift are fetched once for all of them
     const int64_t v_first = ((int64_t)blockIdx.x * 4 + wid) * PPW;
     if (v_first >= m) return;                                // whole wave exits together; no block barrier below
     const int cin = P.cin[0], cout = P.cout[0];
@@ -459,8 +459,8 @@ extern "C" int lvq_pillar_vfe(const float *voxels, const int32_t *num_pts, const
     dim3 grid((unsigned)lvq_cdiv(m_cap, 4)), block(256);
     if (n_layers == 1 && c == 4 && t <= 32 && P.cin[0] <= 12 && P.cout[0] <= 64 && !(((uintptr_t)voxels) & 15) &&
         !lvq_tune().pillar_vfe_generic) {
-        // 4 waves x 4 pillars per workgroup
-        hipLaunchKernelGGL(k_pillar_vfe1, dim3((unsigned)lvq_cdiv(m_cap, 16)), block, 0, lvq_s(stream), reinterpret_cast<const float4 *>(voxels), num_pts, coords_bzyx,
+        // 4 waves x 8 pillars per workgroup
+        hipLaunchKernelGGL(k_pillar_vfe1, dim3((unsigned)lvq_cdiv(m_cap, 32)), block, 0, lvq_s(stream), reinterpret_cast<const float4 *>(voxels), num_pts, coords_bzyx,
                            m_cap, n_voxels_dev, t, P, out);
         return lvq_launch_status();
     }
