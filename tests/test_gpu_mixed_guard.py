@@ -52,15 +52,16 @@ def test_stream_guard_statistic_matches_its_definition():
     assert got[0].max() > 4 * got[1].max()                               # the locked-on head stands out
 
 
+@pytest.mark.parametrize("prec", ["mixed", "mixed16"])
 @pytest.mark.parametrize("scale", [1.0, 4.0, 8.0])
-def test_mixed_mode_holds_the_bar_on_peaked_models(scale, monkeypatch):
+def test_mixed_mode_holds_the_bar_on_peaked_models(scale, prec, monkeypatch):
     """W_q of VATLiDAR block 0's cross-attention scaled by `scale` (scores x scale): at x1 the plain stream is used (both guard halves
     quiet) and meets 1e-3 on the 16 384-key grid; at x4 / x8 the softmax mass moves onto a few occupied cells -- the table statistic
     (empty scene) does not see that, the audit of the scene's own key stream does: the call is redone with hi + lo operands (strict
     mode: inside the call) and meets 1e-3 -- and with the guard disabled the same model is far outside the bar, i.e. the guard is what
     holds it.  Without strict mode a background audit trips the module a call or two later, for that weights version."""
     cfg = small_cfg()
-    pipe = P.FusionPipeline(cfg, DEV, precision="mixed")
+    pipe = P.FusionPipeline(cfg, DEV, precision=prec)
     pipe.vat_lidar.strict_parity = True
     d = cfg.d_model
     with torch.no_grad():
@@ -82,7 +83,7 @@ def test_mixed_mode_holds_the_bar_on_peaked_models(scale, monkeypatch):
         safe = pipe(*batch[:3])
         assert (out["fused"] - safe["fused"]).abs().max().item() > 2 * TOL      # the unguarded plain stream is outside the bar here
         # lagged form: a fresh module of the same weights trips within a few calls and then matches the hi + lo result
-        lag = P.FusionPipeline(cfg, DEV, precision="mixed")
+        lag = P.FusionPipeline(cfg, DEV, precision=prec)
         lag.vat_lidar.load_state_dict(pipe.vat_lidar.state_dict())
         lag.vat_lidar.audit_every = 1
         for _ in range(4):
