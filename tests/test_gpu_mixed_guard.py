@@ -52,8 +52,7 @@ def test_stream_guard_statistic_matches_its_definition():
     assert got[0].max() > 4 * got[1].max()                               # the locked-on head stands out
 
 
-@pytest.mark.parametrize("prec", ["mixed", "mixed16"])
-@pytest.mark.parametrize("scale", [1.0, 4.0, 8.0])
+@pytest.mark.parametrize("scale,prec", [(1.0, "mixed"), (4.0, "mixed"), (8.0, "mixed"), (4.0, "mixed16")])
 def test_mixed_mode_holds_the_bar_on_peaked_models(scale, prec, monkeypatch):
     """W_q of VATLiDAR block 0's cross-attention scaled by `scale` (scores x scale): at x1 the plain stream is used (both guard halves
     quiet) and meets 1e-3 on the 16 384-key grid; at x4 / x8 the softmax mass moves onto a few occupied cells -- the table statistic
